@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PKG = os.path.join(ROOT, "block-lanczos-algorithm-parallelization_amd")
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(PKG, "python")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def has_gpu():
+    try:
+        import blz
+        return blz.device_count() > 0
+    except Exception:
+        return False
