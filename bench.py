@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of block-Lanczos mod p on MI355X, measured as BASELINE.json asks.
+
+A "step" is one pass of the loop body of block_lanczos() (sequential/lanczos_modp.c:631-659):
+two block SpMVs (tmp = M^T v, Av = M tmp), the n x n block inner products, the semi-inverse and the
+row-local block update, all on the GPU with every operand resident in HBM before the clock starts.
+
+  metric  = nnz*n mod-p MAC/s : (2 SpMV * nnz * n) * steps / time   (block products are NOT counted)
+  value   = whole-job rate over all ranks (strong scaling: the matrix is fixed, rows are partitioned)
+  roofline= the SpMV kernel (dominant): algorithmic bytes of SURVEY 8(d) / mean launch duration measured
+            with HIP events on the solver's stream inside this run, against the 8 TB/s HBM3E peak
+  cpu_baseline = the oracle's OpenMP kernels (restating openMP/lanczos_modp.c) timed on this box's
+            host cores on a bounded sample of the SAME workload; a reported baseline, not the target.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run, one
+process per GPU.  torch.distributed (gloo) carries only the control plane (RCCL id, barrier, max of the
+times); the data path's collectives are RCCL calls made by libblz_hip.so on its own stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "block-lanczos-algorithm-parallelization_amd", "python"))
+
+P61 = (1 << 61) - 1
+P31 = (1 << 31) - 1
+# Shapes of BASELINE.json's configs (SuiteSparse headers as recorded in SURVEY 8); the matrices
+# themselves are not on the box, so seeded synthetic stand-ins of the same shape are generated.
+WORKLOADS = {
+    "gl7d19": dict(desc="JGD_GL7d/GL7d19-shape synthetic", rows=1911130, cols=1955309, nnz=37322725, prime=P61,
+                   n=8, right=False, seed=0x474C3764, pattern=False),
+    "relat9": dict(desc="JGD_Relat/relat9-shape synthetic", rows=12360060, cols=549336, nnz=38955420, prime=P61,
+                   n=8, right=True, seed=0x52454C39, pattern=False),
+    "relat8": dict(desc="JGD_Relat/relat8-shape synthetic", rows=345688, cols=12347, nnz=1334038, prime=P31,
+                   n=4, right=False, seed=0x52454C38, pattern=False),
+    "tiny": dict(desc="tiny synthetic (self-test)", rows=20000, cols=15000, nnz=200000, prime=P61,
+                 n=8, right=False, seed=0x54494E59, pattern=False),
+}
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+
+
+def prime_name(p):
+    return {P61: "2^61-1", P31: "2^31-1"}.get(p, str(p))
+
+
+def spmv_alg_bytes(nnz, rows_out, rows_in, n, w, pattern):
+    """every array counted once -- (col_idx + val) per entry, row_ptr, X read, Y written."""
+    return nnz * (4 + (0 if pattern else 4)) + 4 * (rows_out + 1) + (rows_in + rows_out) * n * w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="gl7d19", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    import numpy as np
+    import blz
+    blz.lib()       # load libblz_hip.so (and with it /opt/rocm's HIP runtime) before torch brings its own copy
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo", init_method="env://")
+    if blz.device_count() < 1:
+        sys.exit("bench.py: no GPU visible -- libblz_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+
+    w = WORKLOADS[args.workload]
+    p, n, right = w["prime"], w["n"], w["right"]
+    t0 = time.time()
+    M = blz.Matrix.synth(w["rows"], w["cols"], w["nnz"], w["seed"], p, pattern=w["pattern"])
+    t_gen = time.time() - t0
+
+    ctx = blz.Context(p, n, device=local_rank)
+    if world > 1:
+        uid = [blz.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
+    t0 = time.time()
+    ctx.set_matrix(M, right, rank, world)
+    ctx.init_v()
+    ctx.sync()
+    t_setup = time.time() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warmup, then EXACTLY K steps between barrier + synchronize on both sides -------------
+    if args.warmup > 0:
+        ctx.iterate(args.warmup)
+    ctx.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    done, stopped, dev_ms = ctx.iterate(args.steps)
+    ctx.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if stopped or done != args.steps:
+        sys.exit(f"bench.py: the solve terminated after {done} of {args.steps} steps; use a larger workload")
+
+    # ---- per-kernel durations with HIP events on the solver's stream, same K steps again ---------
+    ctx.profile(True)
+    ctx.iterate(args.steps)
+    prof = ctx.profile_read()
+    ctx.profile(False)
+
+    word = ctx.word_bytes
+    rows_v, rows_t = ctx.rows(blz.V), ctx.rows(blz.TMP)
+    _, loc_v = ctx.local_rows(blz.V)
+    _, loc_t = ctx.local_rows(blz.TMP)
+    # per-rank algorithmic bytes of the two SpMV launches (X is read whole by every rank)
+    csr_first = M.csr(transpose=not right)   # tmp = (right ? M : M^T) v
+    csr_second = M.csr(transpose=right)
+    if world == 1:
+        nnz1 = nnz2 = M.nnz
+    else:
+        bd1, bd2 = csr_first["partition"][world], csr_second["partition"][world]
+        nnz1 = int(csr_first["row_ptr"][bd1[rank + 1]]) - int(csr_first["row_ptr"][bd1[rank]])
+        nnz2 = int(csr_second["row_ptr"][bd2[rank + 1]]) - int(csr_second["row_ptr"][bd2[rank]])
+    pattern = csr_first["val"] is None
+    bytes1 = spmv_alg_bytes(nnz1, loc_t, rows_v, n, word, pattern)
+    bytes2 = spmv_alg_bytes(nnz2, loc_v, rows_t, n, word, pattern)
+    del csr_first, csr_second
+    l1, l2 = prof["spmv1"]["launches"], prof["spmv2"]["launches"]
+    t_spmv_ms = (prof["spmv1"]["ms_total"] + prof["spmv2"]["ms_total"]) / max(l1 + l2, 1)
+    alg_bytes = (bytes1 * l1 + bytes2 * l2) / max(l1 + l2, 1)
+    achieved = alg_bytes / (t_spmv_ms * 1e-3) / 1e9
+    kernels = {k: dict(ms_mean=(v["ms_total"] / v["launches"]) if v["launches"] else None, launches=v["launches"])
+               for k, v in prof.items()}
+    kernels["spmv1"]["alg_bytes"] = bytes1
+    kernels["spmv2"]["alg_bytes"] = bytes2
+    for k_ in ("spmv1", "spmv2"):
+        if kernels[k_]["ms_mean"]:
+            kernels[k_]["alg_GBps"] = kernels[k_]["alg_bytes"] / (kernels[k_]["ms_mean"] * 1e-3) / 1e9
+    kernels["block_dot"]["alg_bytes"] = 2 * loc_v * n * word
+    kernels["orthogonalize"]["alg_bytes"] = 5 * loc_v * n * word
+
+    macs_per_step = 2 * M.nnz * n
+    value = macs_per_step * args.steps / elapsed
+
+    out = {
+        "metric": "nnz*n mod-p MAC/s",
+        "value": value,
+        "unit": "MAC/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u64" if word == 8 else "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{w['desc']}: {w['rows']}x{w['cols']}, {M.nnz} nnz, --prime {prime_name(p)} --n {n} "
+                        f"{'--right' if right else '--left'}",
+            "step": "one block-Lanczos iteration: 2 block SpMV + block_dot + semi_inverse + orthogonalize",
+            "parallelism": "single GPU" if world == 1 else f"row-partition x{world} + RCCL all-gather/all-reduce",
+            "matrix": "seeded synthetic, uniform columns (SURVEY 8(d)); real .mtx not on the box",
+        },
+        "roofline": {
+            "kernel": "k_spmv (both SpMV launches of a step)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "alg_bytes_per_launch": alg_bytes,
+            "ms_per_launch": t_spmv_ms,
+        },
+        "device_ms_per_step": dev_ms / args.steps,
+        "kernels": kernels,
+        "setup_s": {"generate": t_gen, "csr_upload_init": t_setup},
+    }
+
+    # ---- CPU baseline on this box's host cores: bounded sample of the same workload ------------
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as orc
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        Mo = orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+        big = max(rows_v, rows_t) * n
+        v = orc.init_v(rows_v, n, p)
+        tmp, Av, pb = np.zeros(big, np.uint64), np.zeros(rows_v * n, np.uint64), np.zeros(rows_v * n, np.uint64)
+        its, t_cpu = 0, 0.0
+        while True:
+            t0 = time.perf_counter()
+            orc.iteration_omp(Mo, n, p, right, v, tmp, Av, pb, threads)
+            dt = time.perf_counter() - t0
+            its += 1
+            t_cpu += dt
+            if t_cpu + dt > args.cpu_seconds or its >= args.steps:
+                break
+        out["cpu_baseline"] = {
+            "value": macs_per_step * its / t_cpu,
+            "unit": "MAC/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": f"{its} full iteration(s) of the same workload with the oracle's OpenMP kernels "
+                      f"(strategy of openMP/lanczos_modp.c, 128-bit sums), {t_cpu:.1f} s on {os.cpu_count()} host CPUs",
+            "s_per_iteration": t_cpu / its,
+        }
+        # the CPU's first iteration must equal the GPU's first iteration (same seed, same matrix)
+        chk = blz.Context(p, n, device=local_rank)
+        chk.set_matrix(M, right)
+        chk.init_v()
+        chk.iterate(its)
+        same = bool(np.array_equal(chk.get_block(blz.V), v))
+        chk.close()
+        out["cpu_baseline"]["gpu_equals_cpu_after_sample"] = same
+        if not same:
+            sys.exit("bench.py: GPU and CPU baseline disagree after the sampled iterations")
+
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

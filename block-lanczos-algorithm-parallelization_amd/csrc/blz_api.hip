@@ -1,0 +1,756 @@
+/*
+ * blz_api.hip -- the device half of the C ABI declared in include/blz.h: contexts, HBM residency,
+ * kernel sequencing, HIP-event timing and the RCCL exchange steps.
+ *
+ * HBM layout per context (one per GPU).  "side 0" = rows of v/Av/p, "side 1" = rows of tmp.
+ *   blk[V], blk[AV], blk[P] : side 0, blk[TMP] : side 1.  Every block is stored in the rank-major
+ *   padded layout  [rank g][stride rows][n words]  so that an in-place ncclAllGather of the slabs
+ *   yields the operand a CSR slab indexes (its column indices are remapped on the host).  With one
+ *   rank the layout degenerates to the reference's row-major N x n array.
+ *   csr[0] = this rank's rows of M, csr[1] = this rank's rows of M^T.
+ *   small  = [vtAv | vtAAv | winv | d | c | vtAvd], 6*n*n words;  ctl = DevCtl.
+ */
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "blz_internal.h"
+#include "blz_kernels.h"
+
+#define HIPCHK(expr)                                                                                     \
+	do {                                                                                             \
+		hipError_t e_ = (expr);                                                                  \
+		if (e_ != hipSuccess)                                                                    \
+			return blz_fail(BLZ_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+namespace {
+
+struct Rccl {
+	void *handle = nullptr;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+/* RCCL is resolved at run time and only when a communicator is asked for: a single-GPU solve has
+ * no dependency on it.  In a process that already loaded an RCCL (e.g. torch's) that copy is used. */
+int rccl_load()
+{
+	if (g_rccl.handle)
+		return BLZ_OK;
+	const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+	void *h = nullptr;
+	for (const char *nm : names)
+		if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)))
+			break;
+	if (!h)
+		return blz_fail(BLZ_ECOMM, "cannot load librccl: %s", dlerror());
+#define SYM(field, name)                                                                   \
+	*(void **)(&g_rccl.field) = dlsym(h, name);                                        \
+	if (!g_rccl.field)                                                                 \
+		return blz_fail(BLZ_ECOMM, "librccl lacks %s", name);
+	SYM(GetUniqueId, "ncclGetUniqueId")
+	SYM(CommInitRank, "ncclCommInitRank")
+	SYM(CommDestroy, "ncclCommDestroy")
+	SYM(AllGather, "ncclAllGather")
+	SYM(AllReduce, "ncclAllReduce")
+	SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+	g_rccl.handle = h;
+	return BLZ_OK;
+}
+
+#define NCCLCHK(expr)                                                                                     \
+	do {                                                                                              \
+		ncclResult_t r_ = (expr);                                                                 \
+		if (r_ != ncclSuccess)                                                                    \
+			return blz_fail(BLZ_ECOMM, "%s: %s", #expr, g_rccl.GetErrorString(r_));           \
+	} while (0)
+
+}  // namespace
+
+enum { PK_SPMV1 = 0, PK_SPMV2, PK_DOT, PK_SEMI, PK_ORTHO, PK_AG_V, PK_AG_T, PK_AR, PK_COUNT };
+
+struct ProfSpan {
+	int cls;
+	hipEvent_t a, b;
+};
+
+struct blz_ctx {
+	bool profiling = false;
+	std::vector<ProfSpan> spans;
+	std::vector<hipEvent_t> pool;
+	int device = 0;
+	KernelCfg cfg{};
+	u64 prime = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool have_matrix = false;
+	int right = 0, rank = 0, nranks = 1;
+	int64_t glob_rows[2] = { 0, 0 };		/* side 0: N, side 1: C */
+	int64_t first[2] = { 0, 0 }, count[2] = { 0, 0 }, stride[2] = { 0, 0 };
+	std::vector<int64_t> bounds[2];
+	DevCsr csr[2];
+	int row_side[2] = { 0, 1 };			/* side of the rows of csr[t] */
+	void *blk[4] = { nullptr, nullptr, nullptr, nullptr };
+	size_t blk_bytes = 0;
+	u64 *small = nullptr, *partial = nullptr;
+	int max_dot_blocks = 0;
+	DevCtl *ctl = nullptr;
+	DevCtl host_ctl{};
+	ncclComm_t comm = nullptr;
+};
+
+/* HIP-event span around one enqueue on the context's stream (only while profiling is on). */
+struct Span {
+	blz_ctx *c;
+	hipEvent_t b = nullptr;
+	Span(blz_ctx *ctx, int cls) : c(ctx)
+	{
+		if (!c->profiling)
+			return;
+		hipEvent_t ev[2];
+		for (auto &e : ev) {
+			if (!c->pool.empty()) {
+				e = c->pool.back();
+				c->pool.pop_back();
+			} else if (hipEventCreate(&e) != hipSuccess) {
+				return;
+			}
+		}
+		(void)hipEventRecord(ev[0], c->stream);
+		b = ev[1];
+		c->spans.push_back(ProfSpan{ cls, ev[0], ev[1] });
+	}
+	~Span()
+	{
+		if (b)
+			(void)hipEventRecord(b, c->stream);
+	}
+};
+
+static inline int side_of(int block) { return block == BLZ_TMP ? 1 : 0; }
+
+static inline char *slab_ptr(const blz_ctx *c, int block)
+{
+	const int sd = side_of(block);
+	return (char *)c->blk[block] + (size_t)c->rank * c->stride[sd] * c->cfg.n * c->cfg.word;
+}
+
+static void free_csr(DevCsr &A)
+{
+	if (A.row_ptr) hipFree(A.row_ptr);
+	if (A.col_idx) hipFree(A.col_idx);
+	if (A.val) hipFree(A.val);
+	A = DevCsr{};
+}
+
+extern "C" int blz_device_count(void)
+{
+	int cnt = 0;
+	if (hipGetDeviceCount(&cnt) != hipSuccess)
+		return 0;
+	return cnt;
+}
+
+extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
+{
+	if (!out)
+		return blz_fail(BLZ_EINVAL, "blz_create: out is NULL");
+	*out = nullptr;
+	if (n < 1 || n > BLZ_MAX_N)
+		return blz_fail(BLZ_EINVAL, "n = %d is outside 1..%d", n, BLZ_MAX_N);
+	if (prime < 2 || prime >= (1ull << 62))
+		return blz_fail(BLZ_EINVAL, "p must satisfy 2 <= p < 2**62 (the reference's cap of 2**30 - 35 is lifted, "
+				"sequential/lanczos_modp.c:189)");
+	int cnt = 0;
+	if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+		return blz_fail(BLZ_ENOGPU, "no HIP device visible: libblz_hip has no CPU path");
+	if (device < 0 || device >= cnt)
+		return blz_fail(BLZ_EINVAL, "device %d out of range (%d visible)", device, cnt);
+	HIPCHK(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, device));
+	blz_ctx *c = new blz_ctx();
+	c->device = device;
+	c->prime = prime;
+	c->cfg.n = n;
+	c->cfg.word = prime < (1ull << 32) ? 4 : 8;
+	c->cfg.mers = modp_mersenne(prime);
+	c->cfg.m = make_modp(prime);
+	c->cfg.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	HIPCHK(hipEventCreate(&c->ev0));
+	HIPCHK(hipEventCreate(&c->ev1));
+	HIPCHK(hipMalloc(&c->small, small_words(n) * sizeof(u64)));
+	HIPCHK(hipMemset(c->small, 0, small_words(n) * sizeof(u64)));
+	c->max_dot_blocks = c->cfg.num_cu * 2;
+	HIPCHK(hipMalloc(&c->partial, (size_t)c->max_dot_blocks * 2 * n * n * sizeof(u64)));
+	HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
+	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
+	*out = c;
+	return BLZ_OK;
+}
+
+extern "C" void blz_destroy(blz_ctx *c)
+{
+	if (!c)
+		return;
+	hipSetDevice(c->device);
+	if (c->stream)
+		hipStreamSynchronize(c->stream);
+	for (auto &sp : c->spans) {
+		hipEventDestroy(sp.a);
+		hipEventDestroy(sp.b);
+	}
+	for (auto &e : c->pool)
+		hipEventDestroy(e);
+	if (c->comm && g_rccl.CommDestroy)
+		g_rccl.CommDestroy(c->comm);
+	free_csr(c->csr[0]);
+	free_csr(c->csr[1]);
+	for (void *&b : c->blk)
+		if (b) hipFree(b);
+	if (c->small) hipFree(c->small);
+	if (c->partial) hipFree(c->partial);
+	if (c->ctl) hipFree(c->ctl);
+	if (c->ev0) hipEventDestroy(c->ev0);
+	if (c->ev1) hipEventDestroy(c->ev1);
+	if (c->stream) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" int blz_word_bytes(const blz_ctx *c) { return c ? c->cfg.word : 0; }
+
+static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
+{
+	free_csr(D);
+	D.rows = H.rows;
+	D.cols = H.cols;
+	D.nnz = H.nnz;
+	HIPCHK(hipMalloc(&D.row_ptr, (size_t)(H.rows + 1) * sizeof(u32)));
+	HIPCHK(hipMemcpy(D.row_ptr, H.row_ptr, (size_t)(H.rows + 1) * sizeof(u32), hipMemcpyHostToDevice));
+	HIPCHK(hipMalloc(&D.col_idx, (size_t)(H.nnz ? H.nnz : 1) * sizeof(int)));
+	HIPCHK(hipMemcpy(D.col_idx, H.col_idx, (size_t)H.nnz * sizeof(int), hipMemcpyHostToDevice));
+	if (H.val) {
+		HIPCHK(hipMalloc(&D.val, (size_t)(H.nnz ? H.nnz : 1) * sizeof(u32)));
+		HIPCHK(hipMemcpy(D.val, H.val, (size_t)H.nnz * sizeof(u32), hipMemcpyHostToDevice));
+	}
+	(void)c;
+	return BLZ_OK;
+}
+
+extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank, int nranks)
+{
+	if (!c || !M)
+		return blz_fail(BLZ_EINVAL, "blz_set_matrix: NULL argument");
+	if (nranks < 1 || rank < 0 || rank >= nranks)
+		return blz_fail(BLZ_EINVAL, "blz_set_matrix: rank %d of %d", rank, nranks);
+	if (nranks > 1 && (unsigned __int128)nranks * c->prime > ((unsigned __int128)1 << 64))
+		return blz_fail(BLZ_EINVAL, "nranks * p must not exceed 2**64 (u64 all-reduce of residues)");
+	HIPCHK(hipSetDevice(c->device));
+	c->right = right ? 1 : 0;
+	c->rank = rank;
+	c->nranks = nranks;
+	/* side 0 = rows of v: rows of M for a left kernel, columns of M for a right kernel
+	 * (sequential/lanczos_modp.c:592-593). */
+	c->glob_rows[0] = right ? M->ncols : M->nrows;
+	c->glob_rows[1] = right ? M->nrows : M->ncols;
+	c->row_side[0] = right ? 1 : 0;		/* rows of M   */
+	c->row_side[1] = right ? 0 : 1;		/* rows of M^T */
+
+	blz_csr full[2];
+	int rc;
+	if ((rc = blz_csr_from_coo(M, 0, 1, &full[0])) != BLZ_OK)
+		return rc;
+	if ((rc = blz_csr_from_coo(M, 1, 1, &full[1])) != BLZ_OK) {
+		blz_csr_free(&full[0]);
+		return rc;
+	}
+	for (int t = 0; t < 2; t++) {
+		const int sd = c->row_side[t];
+		c->bounds[sd].assign((size_t)nranks + 1, 0);
+		blz_partition_rows(&full[t], nranks, c->bounds[sd].data());
+		int64_t mx = 0;
+		for (int g = 0; g < nranks; g++)
+			mx = std::max<int64_t>(mx, c->bounds[sd][g + 1] - c->bounds[sd][g]);
+		c->stride[sd] = mx;
+		c->first[sd] = c->bounds[sd][rank];
+		c->count[sd] = c->bounds[sd][rank + 1] - c->bounds[sd][rank];
+	}
+	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
+		const int rs = c->row_side[t], cs = 1 - rs;
+		blz_csr slab;
+		if (nranks == 1) {
+			rc = upload_csr(c, full[t], c->csr[t]);
+		} else {
+			rc = blz_csr_slab(&full[t], c->bounds[rs][rank], c->bounds[rs][rank + 1], &slab);
+			if (rc == BLZ_OK) {
+				blz_remap_columns(&slab, c->bounds[cs].data(), nranks, c->stride[cs]);
+				rc = upload_csr(c, slab, c->csr[t]);
+				blz_csr_free(&slab);
+			}
+		}
+	}
+	blz_csr_free(&full[0]);
+	blz_csr_free(&full[1]);
+	if (rc != BLZ_OK)
+		return rc;
+
+	const int64_t rows_max = std::max(c->stride[0], c->stride[1]) * nranks;
+	const size_t bytes = (size_t)std::max<int64_t>(rows_max, 1) * c->cfg.n * c->cfg.word;
+	for (int b = 0; b < 4; b++) {
+		if (c->blk[b])
+			hipFree(c->blk[b]);
+		c->blk[b] = nullptr;
+		HIPCHK(hipMalloc(&c->blk[b], bytes));
+		HIPCHK(hipMemset(c->blk[b], 0, bytes));		/* sequential/lanczos_modp.c:617-622 */
+	}
+	c->blk_bytes = bytes;
+	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
+	c->host_ctl = DevCtl{};
+	c->have_matrix = true;
+	return BLZ_OK;
+}
+
+extern "C" int64_t blz_rows(const blz_ctx *c, int block)
+{
+	return (c && block >= 0 && block < 4) ? c->glob_rows[side_of(block)] : -1;
+}
+
+extern "C" int64_t blz_local_rows(const blz_ctx *c, int block, int64_t *first)
+{
+	if (!c || block < 0 || block > 3)
+		return -1;
+	if (first)
+		*first = c->first[side_of(block)];
+	return c->count[side_of(block)];
+}
+
+/* host u64 words -> device words of the context's width */
+static int put_words(blz_ctx *c, void *dst, const uint64_t *src, int64_t words)
+{
+	if (words <= 0)
+		return BLZ_OK;
+	if (c->cfg.word == 8) {
+		HIPCHK(hipMemcpy(dst, src, (size_t)words * 8, hipMemcpyHostToDevice));
+		return BLZ_OK;
+	}
+	std::vector<u32> tmp((size_t)words);
+	for (int64_t k = 0; k < words; k++)
+		tmp[(size_t)k] = (u32)src[k];
+	HIPCHK(hipMemcpy(dst, tmp.data(), (size_t)words * 4, hipMemcpyHostToDevice));
+	return BLZ_OK;
+}
+
+static int get_words(blz_ctx *c, uint64_t *dst, const void *src, int64_t words)
+{
+	if (words <= 0)
+		return BLZ_OK;
+	if (c->cfg.word == 8) {
+		HIPCHK(hipMemcpy(dst, src, (size_t)words * 8, hipMemcpyDeviceToHost));
+		return BLZ_OK;
+	}
+	std::vector<u32> tmp((size_t)words);
+	HIPCHK(hipMemcpy(tmp.data(), src, (size_t)words * 4, hipMemcpyDeviceToHost));
+	for (int64_t k = 0; k < words; k++)
+		dst[k] = tmp[(size_t)k];
+	return BLZ_OK;
+}
+
+#define NEED_MATRIX(c)                                                                  \
+	do {                                                                            \
+		if (!(c) || !(c)->have_matrix)                                          \
+			return blz_fail(BLZ_EINVAL, "no matrix loaded (blz_set_matrix)"); \
+		HIPCHK(hipSetDevice((c)->device));                                      \
+	} while (0)
+
+extern "C" int blz_set_block(blz_ctx *c, int block, const uint64_t *host)
+{
+	NEED_MATRIX(c);
+	if (block < 0 || block > 3 || !host)
+		return blz_fail(BLZ_EINVAL, "blz_set_block: bad argument");
+	HIPCHK(hipStreamSynchronize(c->stream));
+	const int sd = side_of(block), n = c->cfg.n;
+	for (int g = 0; g < c->nranks; g++) {
+		const int64_t b0 = c->bounds[sd][g], cnt = c->bounds[sd][g + 1] - b0;
+		char *dst = (char *)c->blk[block] + (size_t)g * c->stride[sd] * n * c->cfg.word;
+		int rc = put_words(c, dst, host + b0 * n, cnt * n);
+		if (rc != BLZ_OK)
+			return rc;
+	}
+	return BLZ_OK;
+}
+
+extern "C" int blz_get_block(blz_ctx *c, int block, uint64_t *host)
+{
+	NEED_MATRIX(c);
+	if (block < 0 || block > 3 || !host)
+		return blz_fail(BLZ_EINVAL, "blz_get_block: bad argument");
+	HIPCHK(hipStreamSynchronize(c->stream));
+	const int sd = side_of(block), n = c->cfg.n;
+	return get_words(c, host + c->first[sd] * n, slab_ptr(c, block), c->count[sd] * n);
+}
+
+static int small_off(const blz_ctx *c, int which, int *words)
+{
+	const int nn = c->cfg.n * c->cfg.n;
+	*words = which == BLZ_D ? c->cfg.n : nn;
+	switch (which) {
+	case BLZ_VTAV: return 0;
+	case BLZ_VTAAV: return nn;
+	case BLZ_WINV: return 2 * nn;
+	case BLZ_D: return 3 * nn;
+	default: return -1;
+	}
+}
+
+extern "C" int blz_set_small(blz_ctx *c, int which, const uint64_t *host)
+{
+	if (!c || !host)
+		return blz_fail(BLZ_EINVAL, "blz_set_small: NULL argument");
+	HIPCHK(hipSetDevice(c->device));
+	int words, off = small_off(c, which, &words);
+	if (off < 0)
+		return blz_fail(BLZ_EINVAL, "blz_set_small: unknown operand %d", which);
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemcpy(c->small + off, host, (size_t)words * sizeof(u64), hipMemcpyHostToDevice));
+	return BLZ_OK;
+}
+
+extern "C" int blz_get_small(blz_ctx *c, int which, uint64_t *host)
+{
+	if (!c || !host)
+		return blz_fail(BLZ_EINVAL, "blz_get_small: NULL argument");
+	HIPCHK(hipSetDevice(c->device));
+	int words, off = small_off(c, which, &words);
+	if (off < 0)
+		return blz_fail(BLZ_EINVAL, "blz_get_small: unknown operand %d", which);
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemcpy(host, c->small + off, (size_t)words * sizeof(u64), hipMemcpyDeviceToHost));
+	return BLZ_OK;
+}
+
+extern "C" int blz_init_v(blz_ctx *c)
+{
+	NEED_MATRIX(c);
+	HIPCHK(hipStreamSynchronize(c->stream));
+	for (int b = 0; b < 4; b++)
+		HIPCHK(hipMemset(c->blk[b], 0, c->blk_bytes));
+	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
+	c->host_ctl = DevCtl{};
+	/* :624-625: one sequential stream over the whole block; a rank keeps its rows. */
+	const int n = c->cfg.n;
+	const int64_t skip = c->first[0] * n, keep = c->count[0] * n;
+	std::vector<uint64_t> mine((size_t)std::max<int64_t>(keep, 1));
+	uint64_t s[4];
+	blz_rng_seed(s);
+	for (int64_t k = 0; k < skip; k++)
+		(void)blz_rng_next(s);
+	for (int64_t k = 0; k < keep; k++)
+		mine[(size_t)k] = blz_rng_next(s) % c->prime;
+	return put_words(c, slab_ptr(c, BLZ_V), mine.data(), keep);
+}
+
+/* ---- exchange steps (RCCL over xGMI).  No-ops on a single rank. ---- */
+
+static int allgather_block(blz_ctx *c, int block)
+{
+	if (c->nranks == 1)
+		return BLZ_OK;
+	Span sp(c, block == BLZ_V ? PK_AG_V : PK_AG_T);
+	if (!c->comm)
+		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
+	const int sd = side_of(block);
+	const size_t bytes = (size_t)c->stride[sd] * c->cfg.n * c->cfg.word;
+	NCCLCHK(g_rccl.AllGather(slab_ptr(c, block), c->blk[block], bytes, ncclUint8, c->comm, c->stream));
+	return BLZ_OK;
+}
+
+static int allreduce_dots(blz_ctx *c)
+{
+	if (c->nranks == 1)
+		return BLZ_OK;
+	if (!c->comm)
+		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
+	Span sp(c, PK_AR);
+	/* residues < p < 2^62 and at most 4 ... 8 ranks: for p < 2^61 the u64 sum cannot wrap; the
+	 * semi_inverse kernel reduces it mod p.  (mpi/lanczos_modp.c:1209-1247 does this by hand.) */
+	NCCLCHK(g_rccl.AllReduce(c->small, c->small, (size_t)2 * c->cfg.n * c->cfg.n, ncclUint64, ncclSum, c->comm,
+				 c->stream));
+	return BLZ_OK;
+}
+
+static int enqueue_spmv(blz_ctx *c, int transpose, int src, int dst)
+{
+	Span sp(c, transpose == !c->right ? PK_SPMV1 : PK_SPMV2);
+	HIPCHK(launch_spmv(c->cfg, c->csr[transpose], c->blk[src], slab_ptr(c, dst), c->ctl, c->stream));
+	return BLZ_OK;
+}
+
+static int enqueue_dot(blz_ctx *c)
+{
+	int nb = 0;
+	{
+	Span sp(c, PK_DOT);
+	HIPCHK(launch_block_dot(c->cfg, slab_ptr(c, BLZ_V), slab_ptr(c, BLZ_AV), c->count[0], c->partial,
+				c->max_dot_blocks, &nb, c->ctl, c->stream));
+	HIPCHK(launch_dot_finalize(c->cfg, c->partial, nb, c->small, c->ctl, c->stream));
+	}
+	return allreduce_dots(c);
+}
+
+static int enqueue_ortho(blz_ctx *c)
+{
+	Span sp(c, PK_ORTHO);
+	HIPCHK(launch_orthogonalize(c->cfg, slab_ptr(c, BLZ_V), slab_ptr(c, BLZ_AV), slab_ptr(c, BLZ_P), c->count[0],
+				    c->small, c->ctl, c->stream));
+	return BLZ_OK;
+}
+
+static int fetch_ctl(blz_ctx *c)
+{
+	HIPCHK(hipMemcpyAsync(&c->host_ctl, c->ctl, sizeof(DevCtl), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return BLZ_OK;
+}
+
+extern "C" int blz_spmv(blz_ctx *c, int transpose, int src_block, int dst_block)
+{
+	NEED_MATRIX(c);
+	if (src_block < 0 || src_block > 3 || dst_block < 0 || dst_block > 3 || src_block == dst_block)
+		return blz_fail(BLZ_EINVAL, "blz_spmv: bad block selectors");
+	int rc = enqueue_spmv(c, transpose ? 1 : 0, src_block, dst_block);
+	if (rc != BLZ_OK)
+		return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return BLZ_OK;
+}
+
+extern "C" int blz_block_dot(blz_ctx *c, uint64_t *vtAv, uint64_t *vtAAv)
+{
+	NEED_MATRIX(c);
+	int rc = enqueue_dot(c);
+	if (rc != BLZ_OK)
+		return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	const int nn = c->cfg.n * c->cfg.n;
+	std::vector<u64> h((size_t)2 * nn);
+	HIPCHK(hipMemcpy(h.data(), c->small, (size_t)2 * nn * sizeof(u64), hipMemcpyDeviceToHost));
+	for (int e = 0; e < 2 * nn; e++)
+		h[(size_t)e] %= c->prime;	/* multi-rank sums are reduced by the next kernel; mirror it here */
+	if (vtAv)
+		memcpy(vtAv, h.data(), (size_t)nn * sizeof(u64));
+	if (vtAAv)
+		memcpy(vtAAv, h.data() + nn, (size_t)nn * sizeof(u64));
+	return BLZ_OK;
+}
+
+extern "C" int blz_semi_inverse(blz_ctx *c, int *npiv, uint64_t *winv, uint64_t *d)
+{
+	if (!c)
+		return blz_fail(BLZ_EINVAL, "blz_semi_inverse: NULL context");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(launch_semi_inverse(c->cfg, c->small, c->ctl, 0, c->stream));
+	int rc = fetch_ctl(c);
+	if (rc != BLZ_OK)
+		return rc;
+	if (npiv)
+		*npiv = c->host_ctl.npiv;
+	if (winv && (rc = blz_get_small(c, BLZ_WINV, winv)) != BLZ_OK)
+		return rc;
+	if (d && (rc = blz_get_small(c, BLZ_D, d)) != BLZ_OK)
+		return rc;
+	return BLZ_OK;
+}
+
+extern "C" int blz_orthogonalize(blz_ctx *c)
+{
+	NEED_MATRIX(c);
+	int rc = enqueue_ortho(c);
+	if (rc != BLZ_OK)
+		return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return BLZ_OK;
+}
+
+/* One pass of the loop body, sequential/lanczos_modp.c:635-656, enqueued on the stream. */
+static int enqueue_iteration(blz_ctx *c)
+{
+	int rc;
+	if ((rc = allgather_block(c, BLZ_V)) != BLZ_OK) return rc;
+	if ((rc = enqueue_spmv(c, !c->right, BLZ_V, BLZ_TMP)) != BLZ_OK) return rc;	/* :635 */
+	if ((rc = allgather_block(c, BLZ_TMP)) != BLZ_OK) return rc;
+	if ((rc = enqueue_spmv(c, c->right, BLZ_TMP, BLZ_AV)) != BLZ_OK) return rc;	/* :636 */
+	if ((rc = enqueue_dot(c)) != BLZ_OK) return rc;					/* :640 */
+	{
+		Span sp(c, PK_SEMI);
+		HIPCHK(launch_semi_inverse(c->cfg, c->small, c->ctl, 1, c->stream));	/* :644 */
+	}
+	return enqueue_ortho(c);							/* :652-656 */
+}
+
+extern "C" int blz_iterate(blz_ctx *c, int max_iters, int *done, int *stopped, float *ms)
+{
+	NEED_MATRIX(c);
+	if (max_iters < 0)
+		return blz_fail(BLZ_EINVAL, "blz_iterate: max_iters < 0");
+	const long long before = c->host_ctl.iterations;
+	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	for (int it = 0; it < max_iters; it++) {
+		int rc = enqueue_iteration(c);
+		if (rc != BLZ_OK)
+			return rc;
+	}
+	HIPCHK(hipEventRecord(c->ev1, c->stream));
+	int rc = fetch_ctl(c);
+	if (rc != BLZ_OK)
+		return rc;
+	if (ms)
+		HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+	if (done)
+		*done = (int)(c->host_ctl.iterations - before);
+	if (stopped)
+		*stopped = c->host_ctl.stop;
+	return BLZ_OK;
+}
+
+extern "C" int64_t blz_iterations(const blz_ctx *c) { return c ? c->host_ctl.iterations : -1; }
+
+extern "C" int blz_set_iterations(blz_ctx *c, int64_t iterations)
+{
+	if (!c)
+		return blz_fail(BLZ_EINVAL, "blz_set_iterations: NULL context");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->host_ctl.iterations = iterations;
+	HIPCHK(hipMemcpy(c->ctl, &c->host_ctl, sizeof(DevCtl), hipMemcpyHostToDevice));
+	return BLZ_OK;
+}
+
+extern "C" int blz_final_check(blz_ctx *c, int *v_nonzero, int *vtm_zero)
+{
+	NEED_MATRIX(c);
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemset(&c->ctl->flag_v_nonzero, 0, 2 * sizeof(int)));
+	HIPCHK(launch_any_nonzero(c->cfg, slab_ptr(c, BLZ_V), c->count[0] * c->cfg.n, &c->ctl->flag_v_nonzero, c->stream));
+	HIPCHK(launch_any_nonzero(c->cfg, slab_ptr(c, BLZ_TMP), c->count[1] * c->cfg.n, &c->ctl->flag_t_nonzero, c->stream));
+	if (c->nranks > 1) {
+		if (!c->comm)
+			return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
+		NCCLCHK(g_rccl.AllReduce(&c->ctl->flag_v_nonzero, &c->ctl->flag_v_nonzero, 2, ncclInt32, ncclSum, c->comm,
+					 c->stream));
+	}
+	int rc = fetch_ctl(c);
+	if (rc != BLZ_OK)
+		return rc;
+	if (v_nonzero)
+		*v_nonzero = c->host_ctl.flag_v_nonzero != 0;
+	if (vtm_zero)
+		*vtm_zero = c->host_ctl.flag_t_nonzero == 0;
+	return BLZ_OK;
+}
+
+extern "C" int blz_time_kernel(blz_ctx *c, int which, int reps, float *ms_mean)
+{
+	NEED_MATRIX(c);
+	if (reps < 1 || !ms_mean || which < 0 || which > 3)
+		return blz_fail(BLZ_EINVAL, "blz_time_kernel: bad argument");
+	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	for (int r = 0; r < reps; r++) {
+		int rc = BLZ_OK;
+		switch (which) {
+		case 0: rc = enqueue_spmv(c, !c->right, BLZ_V, BLZ_TMP); break;
+		case 1: rc = enqueue_spmv(c, c->right, BLZ_TMP, BLZ_AV); break;
+		case 2: rc = enqueue_dot(c); break;
+		case 3: rc = enqueue_ortho(c); break;
+		}
+		if (rc != BLZ_OK)
+			return rc;
+	}
+	HIPCHK(hipEventRecord(c->ev1, c->stream));
+	HIPCHK(hipEventSynchronize(c->ev1));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+	*ms_mean = ms / reps;
+	return BLZ_OK;
+}
+
+extern "C" int blz_profile(blz_ctx *c, int enable)
+{
+	if (!c)
+		return blz_fail(BLZ_EINVAL, "blz_profile: NULL context");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	for (auto &sp : c->spans) {
+		c->pool.push_back(sp.a);
+		c->pool.push_back(sp.b);
+	}
+	c->spans.clear();
+	c->profiling = enable != 0;
+	return BLZ_OK;
+}
+
+extern "C" int blz_profile_read(blz_ctx *c, double *ms_sum, int64_t *launches)
+{
+	if (!c || !ms_sum || !launches)
+		return blz_fail(BLZ_EINVAL, "blz_profile_read: NULL argument");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	for (int k = 0; k < PK_COUNT; k++) {
+		ms_sum[k] = 0;
+		launches[k] = 0;
+	}
+	for (auto &sp : c->spans) {
+		float ms = 0;
+		HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b));
+		ms_sum[sp.cls] += ms;
+		launches[sp.cls] += 1;
+	}
+	return BLZ_OK;
+}
+
+extern "C" int blz_sync(blz_ctx *c)
+{
+	if (!c)
+		return blz_fail(BLZ_EINVAL, "blz_sync: NULL context");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return BLZ_OK;
+}
+
+extern "C" int blz_comm_unique_id(void *id_out, size_t id_bytes)
+{
+	if (!id_out || id_bytes < sizeof(ncclUniqueId))
+		return blz_fail(BLZ_EINVAL, "blz_comm_unique_id: need %zu bytes", sizeof(ncclUniqueId));
+	int rc = rccl_load();
+	if (rc != BLZ_OK)
+		return rc;
+	ncclUniqueId id;
+	NCCLCHK(g_rccl.GetUniqueId(&id));
+	memcpy(id_out, &id, sizeof id);
+	return BLZ_OK;
+}
+
+extern "C" int blz_comm_init(blz_ctx *c, const void *id, size_t id_bytes, int rank, int nranks)
+{
+	if (!c || !id || id_bytes < sizeof(ncclUniqueId) || nranks < 1 || rank < 0 || rank >= nranks)
+		return blz_fail(BLZ_EINVAL, "blz_comm_init: bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = rccl_load();
+	if (rc != BLZ_OK)
+		return rc;
+	ncclUniqueId uid;
+	memcpy(&uid, id, sizeof uid);
+	NCCLCHK(g_rccl.CommInitRank(&c->comm, nranks, uid, rank));
+	return BLZ_OK;
+}

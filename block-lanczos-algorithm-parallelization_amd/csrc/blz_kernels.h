@@ -1,0 +1,59 @@
+/* blz_kernels.h -- launchers of the gfx950 kernels (C++ side only; not part of the C ABI). */
+#ifndef BLZ_KERNELS_H
+#define BLZ_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include "modp.h"
+
+/* One CSR slab resident in HBM. */
+struct DevCsr {
+	int64_t rows = 0, cols = 0, nnz = 0;
+	u32 *row_ptr = nullptr;
+	int *col_idx = nullptr;
+	u32 *val = nullptr;	/* nullptr: all ones */
+};
+
+/* Control words shared by all kernels of a context (device memory). */
+struct DevCtl {
+	int stop;		/* set by semi_inverse when npiv == 0: every later kernel is a no-op */
+	int npiv;
+	long long iterations;	/* the reference's n_iterations */
+	int flag_v_nonzero, flag_t_nonzero;
+};
+
+struct KernelCfg {
+	int n;			/* block width */
+	int word;		/* 4 or 8 */
+	int mers;		/* 0, 31, 61 */
+	ModP m;
+	int num_cu;
+};
+
+/* Y[rows x n] = A * X, X addressed through A.col_idx (row-major, n words per row).
+ * sequential/lanczos_modp.c:266-287 */
+hipError_t launch_spmv(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const DevCtl *ctl,
+		       hipStream_t s);
+
+/* partial[b][0..n*n) = sum over block b's rows of v^T Av, partial[b][n*n..2n*n) = Av^T Av.
+ * sequential/lanczos_modp.c:443-453.  Returns the number of partial rows written via *nblocks. */
+hipError_t launch_block_dot(const KernelCfg &c, const void *V, const void *AV, int64_t rows, u64 *partial,
+			    int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s);
+/* out[0..2*n*n) = sum_b partial[b][.] mod p */
+hipError_t launch_dot_finalize(const KernelCfg &c, const u64 *partial, int nblocks, u64 *out, const DevCtl *ctl,
+			       hipStream_t s);
+
+/* small: [vtAv | vtAAv | winv | d | c | vtAvd], n*n words each (d: n words, padded to n*n).
+ * Reads vtAv/vtAAv (reduced mod p first: they may be sums over ranks), writes the rest and
+ * updates ctl.  sequential/lanczos_modp.c:342-438 and :460-475. */
+hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int in_loop, hipStream_t s);
+
+/* Row-local update in place: V <- v', P <- p'.  sequential/lanczos_modp.c:478-491, :655-656 */
+hipError_t launch_orthogonalize(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows,
+				const u64 *small, const DevCtl *ctl, hipStream_t s);
+
+/* flag |= any(X != 0) over `words` words */
+hipError_t launch_any_nonzero(const KernelCfg &c, const void *X, int64_t words, int *flag, hipStream_t s);
+
+static inline size_t small_words(int n) { return (size_t)6 * n * n; }
+
+#endif

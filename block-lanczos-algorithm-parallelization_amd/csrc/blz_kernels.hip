@@ -1,0 +1,547 @@
+/*
+ * blz_kernels.hip -- hand-written gfx950 kernels of the block-Lanczos-mod-p inner iteration.
+ *
+ * Integer, HBM-bound work: no MFMA.  64-lane wavefronts are cut into groups of G = 2^ceil(log2 n)
+ * lanes; one group owns one block row (n consecutive words = one 32/64/128-byte sector), so every
+ * gather of an X row and every store of a Y row is a single coalesced segment.
+ *
+ * Citations are relative to /root/reference/.
+ */
+#include "blz_kernels.h"
+
+#define BLOCK 256
+
+/* ----------------------------------------------------------------------------- SpMV */
+
+/*
+ * sparse_matrix_vector_product(), sequential/lanczos_modp.c:266-287.
+ * The reference scatters COO triplets with a `%` per term (:284).  Here each row of the CSR slab
+ * is reduced by one group of lanes: 128-bit unreduced sum of val*x per column, one reduction per
+ * output word, one coalesced row store.  No atomics, deterministic.
+ */
+template <typename W, int G, int MERS>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
+       const W *__restrict__ X, W *__restrict__ Y, long long rows, int n, ModP m,
+       const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	const int lane = threadIdx.x & (G - 1);
+	const int xl = lane < n ? lane : 0;
+	const long long g0 = ((long long)blockIdx.x * BLOCK + threadIdx.x) / G;
+	const long long ng = (long long)gridDim.x * (BLOCK / G);
+	for (long long r = g0; r < rows; r += ng) {
+		u32 k = rp[r];
+		const u32 e = rp[r + 1];
+		Acc acc;
+		acc_zero(acc);
+		if (va) {
+			for (; k + 4 <= e; k += 4) {
+				const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
+				const u32 a0 = va[k], a1 = va[k + 1], a2 = va[k + 2], a3 = va[k + 3];
+				const W x0 = X[(size_t)c0 * n + xl], x1 = X[(size_t)c1 * n + xl];
+				const W x2 = X[(size_t)c2 * n + xl], x3 = X[(size_t)c3 * n + xl];
+				acc_mac32(acc, a0, x0);
+				acc_mac32(acc, a1, x1);
+				acc_mac32(acc, a2, x2);
+				acc_mac32(acc, a3, x3);
+			}
+			for (; k < e; k++)
+				acc_mac32(acc, va[k], X[(size_t)ci[k] * n + xl]);
+		} else {
+			for (; k + 4 <= e; k += 4) {
+				const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
+				const W x0 = X[(size_t)c0 * n + xl], x1 = X[(size_t)c1 * n + xl];
+				const W x2 = X[(size_t)c2 * n + xl], x3 = X[(size_t)c3 * n + xl];
+				acc_add(acc, x0);
+				acc_add(acc, x1);
+				acc_add(acc, x2);
+				acc_add(acc, x3);
+			}
+			for (; k < e; k++)
+				acc_add(acc, X[(size_t)ci[k] * n + xl]);
+		}
+		if (lane < n)
+			Y[(size_t)r * n + lane] = (W)acc_reduce<MERS>(acc, m);
+	}
+}
+
+template <typename W, int MERS>
+static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const DevCtl *ctl,
+				hipStream_t s)
+{
+	if (A.rows == 0)
+		return hipSuccess;
+	int G = 1;
+	while (G < c.n)
+		G <<= 1;
+	const long long groups_per_block = BLOCK / G;
+	long long blocks = (A.rows + groups_per_block - 1) / groups_per_block;
+	const long long cap = (long long)c.num_cu * 8;
+	if (blocks > cap)
+		blocks = cap;
+#define SPMV_CASE(GG)                                                                                             \
+	case GG:                                                                                                  \
+		hipLaunchKernelGGL((k_spmv<W, GG, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr,  \
+				   A.col_idx, A.val, X, Y, (long long)A.rows, c.n, c.m, ctl);                    \
+		break;
+	switch (G) {
+		SPMV_CASE(1)
+		SPMV_CASE(2)
+		SPMV_CASE(4)
+		SPMV_CASE(8)
+		SPMV_CASE(16)
+		SPMV_CASE(32)
+		SPMV_CASE(64)
+	default:
+		return hipErrorInvalidValue;
+	}
+#undef SPMV_CASE
+	return hipGetLastError();
+}
+
+hipError_t launch_spmv(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const DevCtl *ctl,
+		       hipStream_t s)
+{
+	if (c.word == 4)
+		return c.mers == 31 ? spmv_dispatch<u32, 31>(c, A, (const u32 *)X, (u32 *)Y, ctl, s)
+				    : spmv_dispatch<u32, 0>(c, A, (const u32 *)X, (u32 *)Y, ctl, s);
+	return c.mers == 61 ? spmv_dispatch<u64, 61>(c, A, (const u64 *)X, (u64 *)Y, ctl, s)
+			    : spmv_dispatch<u64, 0>(c, A, (const u64 *)X, (u64 *)Y, ctl, s);
+}
+
+/* --------------------------------------------------------------------- block_dot_products */
+
+/*
+ * block_dot_products() / matmul_CpAtB(), sequential/lanczos_modp.c:443-453, :305-315.
+ * One thread per (i,j) pair and row slice; rows are walked once for both products.
+ * NP = pairs per thread (n*n may exceed the block size for n > 16).
+ */
+template <typename W, int MERS, int NP>
+__global__ void __launch_bounds__(BLOCK)
+k_block_dot(const W *__restrict__ V, const W *__restrict__ AV, long long rows, long long rows_per_block, int n,
+	    ModP m, u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	__shared__ u64 red[2][BLOCK];
+	const int pairs = n * n;
+	const int t = threadIdx.x;
+	const int slices = NP == 1 ? BLOCK / pairs : 1;
+	const int slice = NP == 1 ? t / pairs : 0;
+	const bool live = slice < slices;
+	const long long row0 = (long long)blockIdx.x * rows_per_block;
+	long long row1 = row0 + rows_per_block;
+	if (row1 > rows)
+		row1 = rows;
+	Acc a1[NP], a2[NP];
+	int pi[NP], pj[NP];
+#pragma unroll
+	for (int q = 0; q < NP; q++) {
+		const int e = NP == 1 ? t % pairs : t + q * BLOCK;
+		pi[q] = e < pairs ? e / n : -1;
+		pj[q] = e < pairs ? e % n : 0;
+		acc_zero(a1[q]);
+		acc_zero(a2[q]);
+	}
+	u32 cnt = 0;
+	if (live)
+		for (long long r = row0 + slice; r < row1; r += slices) {
+			const W *vr = V + (size_t)r * n, *ar = AV + (size_t)r * n;
+#pragma unroll
+			for (int q = 0; q < NP; q++)
+				if (pi[q] >= 0) {
+					const u64 vi = vr[pi[q]], ai = ar[pi[q]], aj = ar[pj[q]];
+					acc_mac64(a1[q], vi, aj);
+					acc_mac64(a2[q], ai, aj);
+				}
+			if (++cnt == m.chunk) {
+				cnt = 0;
+#pragma unroll
+				for (int q = 0; q < NP; q++) {
+					acc_set(a1[q], acc_reduce<MERS>(a1[q], m));
+					acc_set(a2[q], acc_reduce<MERS>(a2[q], m));
+				}
+			}
+		}
+	const int nn2 = 2 * pairs;
+	u64 *out = partial + (size_t)blockIdx.x * nn2;
+	if (NP == 1) {
+		red[0][t] = live ? acc_reduce<MERS>(a1[0], m) : 0;
+		red[1][t] = live ? acc_reduce<MERS>(a2[0], m) : 0;
+		__syncthreads();
+		if (t < pairs) {
+			u64 s1 = 0, s2 = 0;
+			for (int sl = 0; sl < slices; sl++) {
+				s1 = addmod(s1, red[0][sl * pairs + t], m.p);
+				s2 = addmod(s2, red[1][sl * pairs + t], m.p);
+			}
+			out[t] = s1;
+			out[pairs + t] = s2;
+		}
+	} else {
+#pragma unroll
+		for (int q = 0; q < NP; q++)
+			if (pi[q] >= 0) {
+				const int e = t + q * BLOCK;
+				out[e] = acc_reduce<MERS>(a1[q], m);
+				out[pairs + e] = acc_reduce<MERS>(a2[q], m);
+			}
+	}
+}
+
+template <typename W, int MERS>
+static hipError_t dot_dispatch(const KernelCfg &c, const W *V, const W *AV, int64_t rows, u64 *partial, int blocks,
+			       long long rpb, const DevCtl *ctl, hipStream_t s)
+{
+	const int pairs = c.n * c.n;
+	if (pairs <= BLOCK)
+		hipLaunchKernelGGL((k_block_dot<W, MERS, 1>), dim3(blocks), dim3(BLOCK), 0, s, V, AV, (long long)rows, rpb,
+				   c.n, c.m, partial, ctl);
+	else if (pairs <= 4 * BLOCK)
+		hipLaunchKernelGGL((k_block_dot<W, MERS, 4>), dim3(blocks), dim3(BLOCK), 0, s, V, AV, (long long)rows, rpb,
+				   c.n, c.m, partial, ctl);
+	else
+		hipLaunchKernelGGL((k_block_dot<W, MERS, 16>), dim3(blocks), dim3(BLOCK), 0, s, V, AV, (long long)rows, rpb,
+				   c.n, c.m, partial, ctl);
+	return hipGetLastError();
+}
+
+hipError_t launch_block_dot(const KernelCfg &c, const void *V, const void *AV, int64_t rows, u64 *partial,
+			    int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
+{
+	long long blocks = (rows + 511) / 512;
+	if (blocks > max_blocks)
+		blocks = max_blocks;
+	if (blocks < 1)
+		blocks = 1;
+	const long long rpb = (rows + blocks - 1) / blocks;
+	*nblocks = (int)blocks;
+	if (c.word == 4)
+		return c.mers == 31 ? dot_dispatch<u32, 31>(c, (const u32 *)V, (const u32 *)AV, rows, partial, (int)blocks, rpb, ctl, s)
+				    : dot_dispatch<u32, 0>(c, (const u32 *)V, (const u32 *)AV, rows, partial, (int)blocks, rpb, ctl, s);
+	return c.mers == 61 ? dot_dispatch<u64, 61>(c, (const u64 *)V, (const u64 *)AV, rows, partial, (int)blocks, rpb, ctl, s)
+			    : dot_dispatch<u64, 0>(c, (const u64 *)V, (const u64 *)AV, rows, partial, (int)blocks, rpb, ctl, s);
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_dot_finalize(const u64 *__restrict__ partial, int nblocks, int words, u64 p, u64 *__restrict__ out,
+	       const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	for (int e = blockIdx.x * BLOCK + threadIdx.x; e < words; e += gridDim.x * BLOCK) {
+		u64 s = 0;
+		for (int b = 0; b < nblocks; b++)
+			s = addmod(s, partial[(size_t)b * words + e], p);
+		out[e] = s;
+	}
+}
+
+hipError_t launch_dot_finalize(const KernelCfg &c, const u64 *partial, int nblocks, u64 *out, const DevCtl *ctl,
+			       hipStream_t s)
+{
+	const int words = 2 * c.n * c.n;
+	const int blocks = (words + BLOCK - 1) / BLOCK;
+	hipLaunchKernelGGL(k_dot_finalize, dim3(blocks), dim3(BLOCK), 0, s, partial, nblocks, words, c.m.p, out, ctl);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- semi_inverse */
+
+/* invmod(), sequential/lanczos_modp.c:318-336 (extended Euclid; |t| <= p < 2^62 throughout). */
+__device__ static u64 dev_invmod(u64 a, u64 p)
+{
+	long long t = 0, nt = 1, r = (long long)p, nr = (long long)(a % p);
+	while (nr != 0) {
+		const long long q = r / nr;
+		long long s = nt;
+		nt = t - q * nt;
+		t = s;
+		s = nr;
+		nr = r - q * nr;
+		r = s;
+	}
+	if (t < 0)
+		t += (long long)p;
+	return (u64)t;
+}
+
+/*
+ * One Gauss-Jordan sweep, lanes = columns.  Pivot rule of sequential/lanczos_modp.c:351-381 and
+ * :393-436: first non-zero entry of column j in rows j..n-1; a column without one is skipped (row j
+ * is then never used as a pivot row later); scale, swap into row j, eliminate.  Returns the pivot
+ * count; *mask gets bit j for every pivot column.  All control flow is wave-uniform.
+ */
+template <int MERS>
+__device__ static int gauss_sweep(u64 *A, u64 *Wm, int n, const ModP &m, u64 *mask)
+{
+	const int lane = threadIdx.x;
+	int found = 0;
+	u64 bits = 0;
+	for (int j = 0; j < n; j++) {
+		__syncthreads();
+		int piv = -1;
+		for (int i = j; i < n; i++)
+			if (A[i * n + j] != 0) {
+				piv = i;
+				break;
+			}
+		if (piv < 0)
+			continue;
+		bits |= 1ull << j;
+		found++;
+		const u64 inv = dev_invmod(A[piv * n + j], m.p);
+		__syncthreads();
+		if (lane < n) {
+			const u64 s = mulmod<MERS>(A[piv * n + lane], inv, m);
+			A[piv * n + lane] = A[j * n + lane];
+			A[j * n + lane] = s;
+			if (Wm) {
+				const u64 w = mulmod<MERS>(Wm[piv * n + lane], inv, m);
+				Wm[piv * n + lane] = Wm[j * n + lane];
+				Wm[j * n + lane] = w;
+			}
+		}
+		__syncthreads();
+		for (int i = 0; i < n; i++) {
+			if (i == j)
+				continue;
+			const u64 mult = A[i * n + j];
+			__syncthreads();
+			if (mult != 0 && lane < n) {
+				const u64 neg = m.p - mult;
+				Acc acc;
+				acc_set(acc, A[i * n + lane]);
+				acc_mac64(acc, neg, A[j * n + lane]);
+				A[i * n + lane] = acc_reduce<MERS>(acc, m);
+				if (Wm) {
+					acc_set(acc, Wm[i * n + lane]);
+					acc_mac64(acc, neg, Wm[j * n + lane]);
+					Wm[i * n + lane] = acc_reduce<MERS>(acc, m);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	*mask = bits;
+	return found;
+}
+
+/*
+ * semi_inverse(), sequential/lanczos_modp.c:342-438, plus the two n x n coefficient matrices that
+ * orthogonalize() derives from it (:460-475), so that the row kernel only streams.
+ * small = [vtAv | vtAAv | winv | d | c | vtAvd].
+ */
+template <int MERS>
+__global__ void __launch_bounds__(64)
+k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, ModP m, int in_loop)
+{
+	/* in_loop = 0: stand-alone call (blz_semi_inverse): neither obeys nor sets the sticky stop flag */
+	if (in_loop && ctl->stop)
+		return;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	u64 *A = (u64 *)smem_raw;
+	u64 *Wm = A + n * n;
+	const int lane = threadIdx.x;
+	const int nn = n * n;
+	u64 *vtAv = small, *vtAAv = small + nn, *winv = small + 2 * nn, *dvec = small + 3 * nn;
+	u64 *cmat = small + 4 * nn, *vtAvd = small + 5 * nn;
+
+	/* inputs may be sums of per-rank residues: bring them back into [0,p) */
+	for (int e = lane; e < nn; e += 64) {
+		const u64 x = reduce128<MERS>(0, vtAv[e], m), y = reduce128<MERS>(0, vtAAv[e], m);
+		vtAv[e] = x;
+		vtAAv[e] = y;
+		A[e] = x;
+	}
+	u64 sel = 0, dbits = 0;
+	gauss_sweep<MERS>(A, nullptr, n, m, &sel);			/* phase 1, :349-382 */
+	for (int e = lane; e < nn; e += 64) {				/* :384-388 */
+		const int i = e / n, j = e % n;
+		const bool both = ((sel >> i) & 1) && ((sel >> j) & 1);
+		A[e] = both ? vtAv[e] : 0;
+		Wm[e] = (i == j && ((sel >> i) & 1)) ? 1 : 0;
+	}
+	const int npiv = gauss_sweep<MERS>(A, Wm, n, m, &dbits);	/* phase 2, :389-436 */
+	for (int e = lane; e < nn; e += 64)
+		winv[e] = Wm[e];
+	if (lane < n)
+		dvec[lane] = (dbits >> lane) & 1;
+	/* c = -(winv * spliced), vtAvd = -vtAv on the selected columns (:462-475), canonical */
+	if (lane < n) {
+		const bool dj = (dbits >> lane) & 1;
+		for (int i = 0; i < n; i++) {
+			u64 acc = 0;
+			for (int k = 0; k < n; k++) {
+				const u64 sp = dj ? vtAAv[k * n + lane] : vtAv[k * n + lane];
+				acc = addmod(acc, mulmod<MERS>(Wm[i * n + k], sp, m), m.p);
+			}
+			cmat[i * n + lane] = acc ? m.p - acc : 0;
+			const u64 x = vtAv[i * n + lane];
+			vtAvd[i * n + lane] = (dj && x) ? m.p - x : 0;
+		}
+	}
+	if (lane == 0) {
+		ctl->npiv = npiv;
+		if (in_loop) {
+			if (npiv == 0)
+				ctl->stop = 1;
+			else
+				ctl->iterations += 1;
+		}
+	}
+}
+
+hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int in_loop, hipStream_t s)
+{
+	const size_t lds = (size_t)2 * c.n * c.n * sizeof(u64);
+#define SEMI(MM)                                                                                                   \
+	do {                                                                                                       \
+		if (lds > 48 * 1024)                                                                               \
+			hipFuncSetAttribute((const void *)k_semi_inverse<MM>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+					    (int)lds);                                                             \
+		hipLaunchKernelGGL((k_semi_inverse<MM>), dim3(1), dim3(64), lds, s, small, ctl, c.n, c.m, in_loop); \
+	} while (0)
+	if (c.mers == 61)
+		SEMI(61);
+	else if (c.mers == 31)
+		SEMI(31);
+	else
+		SEMI(0);
+#undef SEMI
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------ orthogonalize */
+
+/*
+ * orthogonalize() rows, sequential/lanczos_modp.c:478-491, with the copy v <- tmp (:655-656)
+ * folded in: the update is row-local, so v' and p' overwrite v and p in place.
+ *   v'[r,j] = (d[j] ? Av[r,j] : v[r,j]) + sum_k v[r,k] c[k,j] + sum_k p[r,k] vtAvd[k,j]
+ *   p'[r,j] = (d[j] ? 0 : p[r,j])       + sum_k v[r,k] winv[k,j]
+ * One group of G lanes per row; the three n x n matrices and the staged rows live in LDS.
+ */
+template <typename W, int MERS>
+__global__ void __launch_bounds__(BLOCK)
+k_orthogonalize(W *__restrict__ V, const W *__restrict__ AV, W *__restrict__ P, long long rows, int n, int G,
+		ModP m, const u64 *__restrict__ small, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	const int nn = n * n;
+	u64 *sc = (u64 *)smem_raw, *svd = sc + nn, *sw = svd + nn;
+	u64 *sv = sw + nn;			/* [groups][n] */
+	const int gpb = BLOCK / G;
+	u64 *sp = sv + gpb * n;
+	const int t = threadIdx.x, g = t / G, lane = t % G;
+	for (int e = t; e < nn; e += BLOCK) {
+		sw[e] = small[2 * nn + e];
+		sc[e] = small[4 * nn + e];
+		svd[e] = small[5 * nn + e];
+	}
+	const bool dj = lane < n ? small[3 * nn + lane] != 0 : false;
+	for (long long base = (long long)blockIdx.x * gpb; base < rows; base += (long long)gridDim.x * gpb) {
+		const long long r = base + g;
+		const bool ok = r < rows && lane < n;
+		u64 vv = 0, aa = 0, pp = 0;
+		if (ok) {
+			vv = V[(size_t)r * n + lane];
+			aa = AV[(size_t)r * n + lane];
+			pp = P[(size_t)r * n + lane];
+			sv[g * n + lane] = vv;
+			sp[g * n + lane] = pp;
+		}
+		__syncthreads();
+		if (ok) {
+			Acc av, ap;
+			acc_set(av, dj ? aa : vv);
+			acc_set(ap, dj ? 0 : pp);
+			u32 cv = 0, cp = 0;
+			for (int k = 0; k < n; k++) {
+				const u64 vk = sv[g * n + k], pk = sp[g * n + k];
+				acc_mac64(av, vk, sc[k * n + lane]);
+				if (++cv == m.chunk) {
+					cv = 0;
+					acc_set(av, acc_reduce<MERS>(av, m));
+				}
+				acc_mac64(av, pk, svd[k * n + lane]);
+				if (++cv == m.chunk) {
+					cv = 0;
+					acc_set(av, acc_reduce<MERS>(av, m));
+				}
+				acc_mac64(ap, vk, sw[k * n + lane]);
+				if (++cp == m.chunk) {
+					cp = 0;
+					acc_set(ap, acc_reduce<MERS>(ap, m));
+				}
+			}
+			V[(size_t)r * n + lane] = (W)acc_reduce<MERS>(av, m);
+			P[(size_t)r * n + lane] = (W)acc_reduce<MERS>(ap, m);
+		}
+		__syncthreads();
+	}
+}
+
+template <typename W, int MERS>
+static hipError_t ortho_dispatch(const KernelCfg &c, W *V, const W *AV, W *P, int64_t rows, const u64 *small,
+				 const DevCtl *ctl, hipStream_t s)
+{
+	if (rows == 0)
+		return hipSuccess;
+	int G = 1;
+	while (G < c.n)
+		G <<= 1;
+	const int gpb = BLOCK / G;
+	const size_t lds = ((size_t)3 * c.n * c.n + (size_t)2 * gpb * c.n) * sizeof(u64);
+	if (lds > 48 * 1024)
+		hipFuncSetAttribute((const void *)k_orthogonalize<W, MERS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+				    (int)lds);
+	long long blocks = (rows + gpb - 1) / gpb;
+	const long long cap = (long long)c.num_cu * 8;
+	if (blocks > cap)
+		blocks = cap;
+	hipLaunchKernelGGL((k_orthogonalize<W, MERS>), dim3((unsigned)blocks), dim3(BLOCK), lds, s, V, AV, P,
+			   (long long)rows, c.n, G, c.m, small, ctl);
+	return hipGetLastError();
+}
+
+hipError_t launch_orthogonalize(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows,
+				const u64 *small, const DevCtl *ctl, hipStream_t s)
+{
+	if (c.word == 4)
+		return c.mers == 31 ? ortho_dispatch<u32, 31>(c, (u32 *)V, (const u32 *)AV, (u32 *)P, rows, small, ctl, s)
+				    : ortho_dispatch<u32, 0>(c, (u32 *)V, (const u32 *)AV, (u32 *)P, rows, small, ctl, s);
+	return c.mers == 61 ? ortho_dispatch<u64, 61>(c, (u64 *)V, (const u64 *)AV, (u64 *)P, rows, small, ctl, s)
+			    : ortho_dispatch<u64, 0>(c, (u64 *)V, (const u64 *)AV, (u64 *)P, rows, small, ctl, s);
+}
+
+/* ---------------------------------------------------------------------------- utilities */
+
+template <typename W>
+__global__ void __launch_bounds__(BLOCK) k_any_nonzero(const W *__restrict__ X, long long words, int *flag)
+{
+	bool any = false;
+	for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < words; k += (long long)gridDim.x * BLOCK)
+		any |= (X[k] != 0);
+	if (__any(any) && (threadIdx.x & 63) == 0)
+		atomicOr(flag, 1);
+}
+
+hipError_t launch_any_nonzero(const KernelCfg &c, const void *X, int64_t words, int *flag, hipStream_t s)
+{
+	if (words == 0)
+		return hipSuccess;
+	long long blocks = (words + BLOCK - 1) / BLOCK;
+	if (blocks > (long long)c.num_cu * 8)
+		blocks = (long long)c.num_cu * 8;
+	if (c.word == 4)
+		hipLaunchKernelGGL((k_any_nonzero<u32>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (const u32 *)X,
+				   (long long)words, flag);
+	else
+		hipLaunchKernelGGL((k_any_nonzero<u64>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (const u64 *)X,
+				   (long long)words, flag);
+	return hipGetLastError();
+}

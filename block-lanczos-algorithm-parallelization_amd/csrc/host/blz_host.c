@@ -1,0 +1,562 @@
+/*
+ * blz_host.c -- the plain-C host side of libblz_hip.so: MatrixMarket ingest, CSR construction,
+ * row partitioning, the fixed-seed generator, the result writer and checkpoint files.
+ * Nothing here touches the GPU.  Reference citations are relative to /root/reference/.
+ */
+#define _GNU_SOURCE
+#include "../blz_internal.h"
+
+#include <ctype.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+/* ---------------------------------------------------------------------------- errors */
+
+static __thread char g_err[512];
+
+int blz_fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+const char *blz_last_error(void) { return g_err; }
+int blz_version(void) { return 100; }
+
+/* ------------------------------------------------------------------ MatrixMarket ingest */
+
+/* One pass over a memory-mapped file: no stdio, no per-entry locale work.  The grammar is
+ * what fscanf("%d %d %d\n") accepts (sequential/lanczos_modp.c:239): optional blanks, optional
+ * sign, decimal digits. */
+typedef struct {
+	const char *p, *end;
+} cursor;
+
+static int next_line(cursor *c, char *buf, size_t cap)
+{
+	if (c->p >= c->end)
+		return -1;
+	const char *nl = memchr(c->p, '\n', (size_t)(c->end - c->p));
+	const char *stop = nl ? nl : c->end;
+	size_t len = (size_t)(stop - c->p);
+	if (len >= cap)
+		len = cap - 1;
+	memcpy(buf, c->p, len);
+	buf[len] = 0;
+	c->p = nl ? nl + 1 : c->end;
+	return 0;
+}
+
+static inline int next_int(cursor *c, long long *out)
+{
+	const char *p = c->p, *end = c->end;
+	while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f'))
+		p++;
+	if (p >= end)
+		return -1;
+	int neg = 0;
+	if (*p == '-' || *p == '+') {
+		neg = (*p == '-');
+		p++;
+	}
+	if (p >= end || *p < '0' || *p > '9')
+		return -1;
+	unsigned long long acc = 0;
+	while (p < end && *p >= '0' && *p <= '9')
+		acc = acc * 10 + (unsigned)(*p++ - '0');
+	*out = neg ? -(long long)acc : (long long)acc;
+	c->p = p;
+	return 0;
+}
+
+static void lowercase(char *s)
+{
+	for (; *s; s++)
+		*s = (char)tolower((unsigned char)*s);
+}
+
+/* mm_read_banner(), mmio.c:28-111, and the type tests of sequential/lanczos_modp.c:214-221. */
+static int check_banner(const char *line, int want_array)
+{
+	char tok[5][64];
+	if (sscanf(line, "%63s %63s %63s %63s %63s", tok[0], tok[1], tok[2], tok[3], tok[4]) != 5)
+		return blz_fail(BLZ_EFORMAT, "Could not process Matrix Market banner.");
+	for (int k = 1; k < 5; k++)
+		lowercase(tok[k]);
+	if (strncmp(tok[0], "%%MatrixMarket", 14) != 0 || strcmp(tok[1], "matrix") != 0)
+		return blz_fail(BLZ_EFORMAT, "Could not process Matrix Market banner.");
+	const int sparse = strcmp(tok[2], "coordinate") == 0, dense = strcmp(tok[2], "array") == 0;
+	const int known_type = !strcmp(tok[3], "real") || !strcmp(tok[3], "complex") || !strcmp(tok[3], "pattern")
+	    || !strcmp(tok[3], "integer");
+	const int known_sym = !strcmp(tok[4], "general") || !strcmp(tok[4], "symmetric")
+	    || !strcmp(tok[4], "hermitian") || !strcmp(tok[4], "skew-symmetric");
+	if ((!sparse && !dense) || !known_type || !known_sym)
+		return blz_fail(BLZ_EFORMAT, "Could not process Matrix Market banner.");
+	if (want_array ? !dense : !sparse)
+		return blz_fail(BLZ_EFORMAT, "Matrix Market type: [%s %s %s %s] not supported (only %s matrices are OK)",
+				tok[1], tok[2], tok[3], tok[4], want_array ? "dense" : "sparse");
+	if (strcmp(tok[3], "integer") != 0 || strcmp(tok[4], "general") != 0)
+		return blz_fail(BLZ_EFORMAT, "Matrix type [%s %s %s %s] not supported (only integer general are OK)",
+				tok[1], tok[2], tok[3], tok[4]);
+	return BLZ_OK;
+}
+
+int blz_mm_load(const char *path, uint64_t prime, blz_coo *out)
+{
+	if (!path || !out || prime < 2)
+		return blz_fail(BLZ_EINVAL, "blz_mm_load: bad argument");
+	memset(out, 0, sizeof *out);
+	int fd = open(path, O_RDONLY);
+	if (fd < 0)
+		return blz_fail(BLZ_EIO, "impossible d'ouvrir %s: %s", path, strerror(errno));
+	struct stat st;
+	if (fstat(fd, &st) != 0 || st.st_size == 0) {
+		close(fd);
+		return blz_fail(BLZ_EFORMAT, "Could not process Matrix Market banner.");
+	}
+	char *base = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (base == MAP_FAILED)
+		return blz_fail(BLZ_EIO, "mmap %s: %s", path, strerror(errno));
+	madvise(base, (size_t)st.st_size, MADV_SEQUENTIAL);
+	cursor c = { base, base + st.st_size };
+	char line[1100];
+	int rc = BLZ_OK;
+	if (next_line(&c, line, sizeof line) || (rc = check_banner(line, 0)) != BLZ_OK) {
+		munmap(base, (size_t)st.st_size);
+		return rc ? rc : blz_fail(BLZ_EFORMAT, "Could not process Matrix Market banner.");
+	}
+	/* mm_read_mtx_crd_size(), mmio.c:113-141 */
+	long long nr = 0, nc = 0, nz = 0;
+	do {
+		if (next_line(&c, line, sizeof line)) {
+			munmap(base, (size_t)st.st_size);
+			return blz_fail(BLZ_EIO, "Cannot read matrix size");
+		}
+	} while (line[0] == '%');
+	if (sscanf(line, "%lld %lld %lld", &nr, &nc, &nz) != 3) {
+		if (next_int(&c, &nr) || next_int(&c, &nc) || next_int(&c, &nz)) {
+			munmap(base, (size_t)st.st_size);
+			return blz_fail(BLZ_EIO, "Cannot read matrix size");
+		}
+	}
+	if (nr < 0 || nc < 0 || nz < 0 || nr > INT32_MAX || nc > INT32_MAX) {
+		munmap(base, (size_t)st.st_size);
+		return blz_fail(BLZ_EIO, "Cannot read matrix size");
+	}
+	out->nrows = nr;
+	out->ncols = nc;
+	out->nnz = nz;
+	const size_t cap = (size_t)(nz ? nz : 1);
+	out->i = malloc(cap * sizeof *out->i);
+	out->j = malloc(cap * sizeof *out->j);
+	out->x = malloc(cap * sizeof *out->x);
+	if (!out->i || !out->j || !out->x) {
+		munmap(base, (size_t)st.st_size);
+		blz_coo_free(out);
+		return blz_fail(BLZ_ENOMEM, "Cannot allocate sparse matrix");
+	}
+	for (long long u = 0; u < nz; u++) {
+		long long a, b, v;
+		if (next_int(&c, &a) || next_int(&c, &b) || next_int(&c, &v)) {
+			munmap(base, (size_t)st.st_size);
+			blz_coo_free(out);
+			return blz_fail(BLZ_EIO, "parse error entry %lld", u);
+		}
+		if (a < 1 || a > nr || b < 1 || b > nc) {
+			munmap(base, (size_t)st.st_size);
+			blz_coo_free(out);
+			return blz_fail(BLZ_EIO, "entry %lld: index (%lld, %lld) outside %lld x %lld", u, a, b, nr, nc);
+		}
+		out->i[u] = (int32_t)(a - 1);	/* MatrixMarket is 1-based, :241-242 */
+		out->j[u] = (int32_t)(b - 1);
+		/* :238-243: "%d" into a u32, then % prime */
+		out->x[u] = (uint32_t)((uint64_t)(uint32_t)(int32_t)v % prime);
+	}
+	munmap(base, (size_t)st.st_size);
+	return BLZ_OK;
+}
+
+void blz_coo_free(blz_coo *M)
+{
+	if (!M)
+		return;
+	free(M->i);
+	free(M->j);
+	free(M->x);
+	memset(M, 0, sizeof *M);
+}
+
+/* ------------------------------------------------------------------ synthetic matrices */
+
+static inline uint64_t splitmix64(uint64_t *s)
+{
+	uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+int blz_synth_coo(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int pattern, uint64_t prime,
+		  blz_coo *out)
+{
+	static const int32_t palette[7] = { 1, 1, 1, 2, 3, -1, -2 };
+	if (!out || nrows <= 0 || ncols <= 0 || nnz < 0 || prime < 2 || nrows > INT32_MAX || ncols > INT32_MAX)
+		return blz_fail(BLZ_EINVAL, "blz_synth_coo: bad shape");
+	const int64_t base = nnz / nrows, extra = nnz % nrows;
+	if (base + (extra ? 1 : 0) > ncols)
+		return blz_fail(BLZ_EINVAL, "blz_synth_coo: more entries per row than columns");
+	memset(out, 0, sizeof *out);
+	out->nrows = nrows;
+	out->ncols = ncols;
+	out->nnz = nnz;
+	const size_t cap = (size_t)(nnz ? nnz : 1);
+	out->i = malloc(cap * sizeof *out->i);
+	out->j = malloc(cap * sizeof *out->j);
+	out->x = malloc(cap * sizeof *out->x);
+	if (!out->i || !out->j || !out->x) {
+		blz_coo_free(out);
+		return blz_fail(BLZ_ENOMEM, "blz_synth_coo: out of memory");
+	}
+#pragma omp parallel for schedule(static)
+	for (int64_t r = 0; r < nrows; r++) {
+		const int64_t cnt = base + (r < extra);
+		int64_t at = r * base + (r < extra ? r : extra);
+		uint64_t s = seed ^ ((uint64_t)r * 0xD1342543DE82EF95ull);
+		for (int64_t k = 0; k < cnt; k++) {
+			int32_t col;
+			for (;;) {	/* distinct columns within the row */
+				col = (int32_t)(splitmix64(&s) % (uint64_t)ncols);
+				int dup = 0;
+				for (int64_t q = at - k; q < at && !dup; q++)
+					dup = (out->j[q] == col);
+				if (!dup)
+					break;
+			}
+			const int32_t v = pattern ? 1 : palette[splitmix64(&s) % 7];
+			out->i[at] = (int32_t)r;
+			out->j[at] = col;
+			out->x[at] = (uint32_t)((uint64_t)(uint32_t)v % prime);
+			at++;
+		}
+	}
+	return BLZ_OK;
+}
+
+/* ------------------------------------------------------------------------ CSR building */
+
+void blz_csr_free(blz_csr *A)
+{
+	if (!A)
+		return;
+	free(A->row_ptr);
+	free(A->col_idx);
+	free(A->val);
+	memset(A, 0, sizeof *A);
+}
+
+/* Counting sort by row (or by column for the transpose); stable, so entries of one row keep
+ * file order.  Order is irrelevant to the result: every output word is the canonical residue
+ * of an exact integer sum. */
+int blz_csr_from_coo(const blz_coo *M, int transpose, int pattern, blz_csr *out)
+{
+	if (!M || !out)
+		return blz_fail(BLZ_EINVAL, "blz_csr_from_coo: bad argument");
+	if (M->nnz >= (int64_t)UINT32_MAX)
+		return blz_fail(BLZ_EINVAL, "blz_csr_from_coo: nnz >= 2^32 per slab is not supported");
+	memset(out, 0, sizeof *out);
+	const int64_t rows = transpose ? M->ncols : M->nrows;
+	const int32_t *ri = transpose ? M->j : M->i, *ci = transpose ? M->i : M->j;
+	out->rows = rows;
+	out->cols = transpose ? M->nrows : M->ncols;
+	out->nnz = M->nnz;
+	out->row_ptr = calloc((size_t)rows + 2, sizeof *out->row_ptr);
+	out->col_idx = malloc((size_t)(M->nnz ? M->nnz : 1) * sizeof *out->col_idx);
+	int ones = pattern != 0;
+	if (ones)
+		for (int64_t k = 0; k < M->nnz && ones; k++)
+			ones = (M->x[k] == 1);
+	out->val = ones ? NULL : malloc((size_t)(M->nnz ? M->nnz : 1) * sizeof *out->val);
+	if (!out->row_ptr || !out->col_idx || (!ones && !out->val)) {
+		blz_csr_free(out);
+		return blz_fail(BLZ_ENOMEM, "blz_csr_from_coo: out of memory");
+	}
+	uint32_t *next = out->row_ptr + 1;	/* next[r] will become the start of row r */
+	for (int64_t k = 0; k < M->nnz; k++)
+		next[ri[k] + 1]++;
+	for (int64_t r = 0; r < rows; r++)
+		next[r + 1] += next[r];		/* next[r] = start(r), next[rows] = nnz */
+	for (int64_t k = 0; k < M->nnz; k++) {
+		const uint32_t at = next[ri[k]]++;
+		out->col_idx[at] = ci[k];
+		if (out->val)
+			out->val[at] = M->x[k];
+	}
+	/* after the scatter next[r] = start(r+1) = row_ptr[r+1]; row_ptr[0] is already 0 */
+	return BLZ_OK;
+}
+
+int blz_partition_rows(const blz_csr *A, int parts, int64_t *bounds)
+{
+	if (!A || parts < 1 || !bounds)
+		return blz_fail(BLZ_EINVAL, "blz_partition_rows: bad argument");
+	/* weight of a row = its entries + 1 (so that empty rows are spread too) */
+	const double total = (double)A->nnz + (double)A->rows;
+	int64_t r = 0;
+	bounds[0] = 0;
+	for (int g = 1; g < parts; g++) {
+		const double target = total * g / parts;
+		while (r < A->rows && (double)A->row_ptr[r + 1] + (double)(r + 1) <= target)
+			r++;
+		bounds[g] = r;
+	}
+	bounds[parts] = A->rows;
+	return BLZ_OK;
+}
+
+int blz_csr_slab(const blz_csr *A, int64_t r0, int64_t r1, blz_csr *out)
+{
+	memset(out, 0, sizeof *out);
+	const uint32_t lo = A->row_ptr[r0], hi = A->row_ptr[r1];
+	out->rows = r1 - r0;
+	out->cols = A->cols;
+	out->nnz = (int64_t)hi - lo;
+	out->row_ptr = malloc((size_t)(out->rows + 1) * sizeof *out->row_ptr);
+	out->col_idx = malloc((size_t)(out->nnz ? out->nnz : 1) * sizeof *out->col_idx);
+	out->val = A->val ? malloc((size_t)(out->nnz ? out->nnz : 1) * sizeof *out->val) : NULL;
+	if (!out->row_ptr || !out->col_idx || (A->val && !out->val)) {
+		blz_csr_free(out);
+		return blz_fail(BLZ_ENOMEM, "blz_csr_slab: out of memory");
+	}
+	for (int64_t r = 0; r <= out->rows; r++)
+		out->row_ptr[r] = A->row_ptr[r0 + r] - lo;
+	memcpy(out->col_idx, A->col_idx + lo, (size_t)out->nnz * sizeof *out->col_idx);
+	if (A->val)
+		memcpy(out->val, A->val + lo, (size_t)out->nnz * sizeof *out->val);
+	return BLZ_OK;
+}
+
+void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t stride)
+{
+	if (parts == 1)
+		return;
+	for (int64_t k = 0; k < A->nnz; k++) {
+		const int64_t c = A->col_idx[k];
+		int lo = 0, hi = parts - 1;	/* largest g with bounds[g] <= c */
+		while (lo < hi) {
+			const int mid = (lo + hi + 1) / 2;
+			if (bounds[mid] <= c)
+				lo = mid;
+			else
+				hi = mid - 1;
+		}
+		A->col_idx[k] = (int32_t)(lo * stride + (c - bounds[lo]));
+	}
+}
+
+/* --------------------------------------------------------------------------------- RNG */
+
+/* sequential/lanczos_modp.c:67 */
+void blz_rng_seed(uint64_t s[4])
+{
+	s[0] = 0x1415926535ull;
+	s[1] = 0x8979323846ull;
+	s[2] = 0x2643383279ull;
+	s[3] = 0x5028841971ull;
+}
+
+/* sequential/lanczos_modp.c:69-87 */
+uint64_t blz_rng_next(uint64_t s[4])
+{
+	const uint64_t sum = s[0] + s[3];
+	const uint64_t result = ((sum << 23) | (sum >> 41)) + s[0];
+	const uint64_t t = s[1] << 17;
+	s[2] ^= s[0];
+	s[3] ^= s[1];
+	s[1] ^= s[2];
+	s[0] ^= s[3];
+	s[2] ^= t;
+	s[3] = (s[3] << 45) | (s[3] >> 19);
+	return result;
+}
+
+int blz_rng_fill(uint64_t *v, int64_t words, uint64_t prime)
+{
+	if (!v || words < 0 || prime < 2)
+		return blz_fail(BLZ_EINVAL, "blz_rng_fill: bad argument");
+	uint64_t s[4];
+	blz_rng_seed(s);
+	for (int64_t k = 0; k < words; k++)
+		v[k] = blz_rng_next(s) % prime;
+	return BLZ_OK;
+}
+
+/* ---------------------------------------------------------------------- result writer */
+
+int blz_save_block(const char *path, int64_t nrows, int n, const uint64_t *v)
+{
+	FILE *f = fopen(path, "w");
+	if (!f)
+		return blz_fail(BLZ_EIO, "cannot open %s: %s", path, strerror(errno));
+	static char iobuf[1 << 20];
+	setvbuf(f, iobuf, _IOFBF, sizeof iobuf);
+	fprintf(f, "%%%%MatrixMarket matrix array integer general\n");
+	fprintf(f, "%%block of left-kernel vector computed by lanczos_modp\n");
+	fprintf(f, "%ld %d\n", (long)nrows, n);
+	for (int col = 0; col < n; col++)
+		for (int64_t r = 0; r < nrows; r++) {
+			const uint64_t w = v[r * n + col];
+			if (w < 0x100000000ull)
+				fprintf(f, "%d\n", (int)(uint32_t)w);	/* the reference's "%d" of a u32 */
+			else
+				fprintf(f, "%llu\n", (unsigned long long)w);
+		}
+	if (fclose(f))
+		return blz_fail(BLZ_EIO, "write error on %s", path);
+	return BLZ_OK;
+}
+
+/* -------------------------------------------------------------------------- checkpoints */
+
+typedef struct {
+	char magic[8];		/* "BLZCKPT1" */
+	uint64_t prime;
+	int64_t nrows, iterations;
+	int32_t n, right;
+} ckpt_header;
+
+int blz_checkpoint_save(const char *path, uint64_t prime, int n, int right, int64_t nrows, int64_t iterations,
+			const uint64_t *v, const uint64_t *p)
+{
+	char tmp[4096];
+	snprintf(tmp, sizeof tmp, "%s.tmp.%d", path, (int)getpid());
+	FILE *f = fopen(tmp, "wb");
+	if (!f)
+		return blz_fail(BLZ_EIO, "cannot open %s: %s", tmp, strerror(errno));
+	ckpt_header h;
+	memset(&h, 0, sizeof h);
+	memcpy(h.magic, "BLZCKPT1", 8);
+	h.prime = prime;
+	h.nrows = nrows;
+	h.iterations = iterations;
+	h.n = n;
+	h.right = right;
+	const size_t words = (size_t)(nrows * n);
+	int ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(v, sizeof *v, words, f) == words
+	    && fwrite(p, sizeof *p, words, f) == words && fflush(f) == 0 && fsync(fileno(f)) == 0;
+	ok = (fclose(f) == 0) && ok;
+	if (!ok || rename(tmp, path) != 0) {
+		unlink(tmp);
+		return blz_fail(BLZ_EIO, "cannot write checkpoint %s: %s", path, strerror(errno));
+	}
+	return BLZ_OK;
+}
+
+int blz_checkpoint_load(const char *path, uint64_t prime, int n, int right, int64_t nrows, int64_t *iterations,
+			uint64_t *v, uint64_t *p)
+{
+	FILE *f = fopen(path, "rb");
+	if (!f)
+		return blz_fail(BLZ_EIO, "cannot open %s: %s", path, strerror(errno));
+	ckpt_header h;
+	const size_t words = (size_t)(nrows * n);
+	int ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "BLZCKPT1", 8) == 0;
+	if (ok && (h.prime != prime || h.n != n || h.right != right || h.nrows != nrows)) {
+		fclose(f);
+		return blz_fail(BLZ_EINVAL, "checkpoint %s was written for another prime/n/orientation/shape", path);
+	}
+	ok = ok && fread(v, sizeof *v, words, f) == words && fread(p, sizeof *p, words, f) == words;
+	fclose(f);
+	if (!ok)
+		return blz_fail(BLZ_EIO, "checkpoint %s is truncated or not a checkpoint", path);
+	*iterations = h.iterations;
+	return BLZ_OK;
+}
+
+/* The reference's text snapshot, openMP/lanczos_modp.c:571-601: one "%d" per line,
+ * block_size_pad lines per vector (padding rows are zero). */
+static int64_t ref_block_size_pad(int n, int64_t nrows, int64_t ncols)
+{
+	const int64_t a = (nrows + n - 1) / n * n, b = (ncols + n - 1) / n * n;
+	return (a > b ? a : b) * n;		/* sequential/lanczos_modp.c:595-597 */
+}
+
+static int write_ref_vector(const char *dir, const char *name, int64_t pad, int64_t words, const uint64_t *v)
+{
+	char path[4096];
+	snprintf(path, sizeof path, "%s/%s", dir, name);
+	FILE *f = fopen(path, "w");
+	if (!f)
+		return blz_fail(BLZ_EIO, "cannot open %s: %s", path, strerror(errno));
+	for (int64_t k = 0; k < pad; k++)
+		fprintf(f, "%d\n", k < words ? (int)(uint32_t)v[k] : 0);
+	return fclose(f) ? blz_fail(BLZ_EIO, "write error on %s", path) : BLZ_OK;
+}
+
+int blz_checkpoint_save_ref_text(const char *dir, int n, int64_t nrows, int64_t ncols, int64_t iterations,
+				 double start, double now, const uint64_t *v, const uint64_t *tmp,
+				 const uint64_t *Av, const uint64_t *p)
+{
+	const int64_t pad = ref_block_size_pad(n, nrows, ncols);
+	char path[4096];
+	snprintf(path, sizeof path, "%s/verbosity.txt", dir);
+	FILE *f = fopen(path, "w");
+	if (!f)
+		return blz_fail(BLZ_EIO, "cannot open %s: %s", path, strerror(errno));
+	fprintf(f, "%d\n%f\n%f\n", (int)iterations, start, now);	/* openMP/lanczos_modp.c:603-620 */
+	if (fclose(f))
+		return blz_fail(BLZ_EIO, "write error on %s", path);
+	int rc;
+	if ((rc = write_ref_vector(dir, "v.txt", pad, nrows * n, v)) ||
+	    (rc = write_ref_vector(dir, "tmp.txt", pad, ncols * n, tmp)) ||
+	    (rc = write_ref_vector(dir, "Av.txt", pad, nrows * n, Av)) ||
+	    (rc = write_ref_vector(dir, "p.txt", pad, nrows * n, p)))
+		return rc;
+	return BLZ_OK;
+}
+
+static int read_ref_vector(const char *dir, const char *name, int64_t words, uint64_t *v)
+{
+	char path[4096], line[128];
+	snprintf(path, sizeof path, "%s/%s", dir, name);
+	FILE *f = fopen(path, "r");
+	if (!f)
+		return blz_fail(BLZ_EIO, "cannot open %s: %s", path, strerror(errno));
+	int64_t k = 0;
+	while (fgets(line, sizeof line, f)) {	/* openMP/lanczos_modp.c:622-647: atoi per line */
+		if (k < words)
+			v[k] = (uint64_t)(uint32_t)atoi(line);
+		k++;
+	}
+	fclose(f);
+	if (k < words)
+		return blz_fail(BLZ_EIO, "%s holds %ld words, %ld needed", path, (long)k, (long)words);
+	return BLZ_OK;
+}
+
+int blz_checkpoint_load_ref_text(const char *dir, int n, int64_t nrows, int64_t ncols, int64_t *iterations,
+				 uint64_t *v, uint64_t *p)
+{
+	(void)ncols;
+	char path[4096], line[128];
+	snprintf(path, sizeof path, "%s/verbosity.txt", dir);
+	FILE *f = fopen(path, "r");
+	if (!f)
+		return blz_fail(BLZ_EIO, "cannot open %s: %s", path, strerror(errno));
+	*iterations = fgets(line, sizeof line, f) ? atoi(line) : 0;	/* openMP/lanczos_modp.c:661-664 */
+	fclose(f);
+	int rc;
+	if ((rc = read_ref_vector(dir, "v.txt", nrows * n, v)) || (rc = read_ref_vector(dir, "p.txt", nrows * n, p)))
+		return rc;
+	return BLZ_OK;
+}

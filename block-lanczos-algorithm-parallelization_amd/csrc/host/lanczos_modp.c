@@ -1,0 +1,270 @@
+/*
+ * lanczos_modp -- drop-in for the reference's command-line program, driving the MI355X kernels
+ * through the C ABI of include/blz.h.  Plain C host code; no GPU code in this file.
+ *
+ * Same flags, same MatrixMarket input rules, same output file and the same key stdout lines as
+ * sequential/lanczos_modp.c (main :690-705, options :141-194) plus the checkpoint flags of
+ * openMP/lanczos_modp.c:189-243.  Differences, all stated in --help:
+ *   - the prime may be anything in [2, 2^62) (the reference stops at 2^30-35, :189-193);
+ *   - checkpoints are one binary file written atomically (lanczos_modp.ckpt in the CWD);
+ *     with BLZ_REF_CHECKPOINT=1 and p < 2^32 the reference's five text files are written too, and
+ *     --load-checkpoint falls back to them when the binary file is absent.
+ */
+#define _GNU_SOURCE
+#include <err.h>
+#include <getopt.h>
+#include <inttypes.h>
+#include <stdbool.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "blz.h"
+
+static long n = 1;
+static uint64_t prime;
+static char *matrix_filename, *kernel_filename;
+static bool right_kernel, checkpoints, load_checkpoint;
+static int stop_after = -1, checkpoint_timer = 60, device;
+
+static double wtime(void)
+{
+	struct timeval ts;
+	gettimeofday(&ts, NULL);
+	return (double)ts.tv_sec + ts.tv_usec / 1e6;
+}
+
+/* human_format(), sequential/lanczos_modp.c:99-120 */
+static void human_format(char *target, long v)
+{
+	if (v < 1000)
+		sprintf(target, "%ld", v);
+	else if (v < 1000000)
+		sprintf(target, "%.1fK", v / 1e3);
+	else if (v < 1000000000)
+		sprintf(target, "%.1fM", v / 1e6);
+	else if (v < 1000000000000ll)
+		sprintf(target, "%.1fG", v / 1e9);
+	else
+		sprintf(target, "%.1fT", v / 1e12);
+}
+
+static void usage(char **argv)
+{
+	printf("%s [OPTIONS]\n\n", argv[0]);
+	printf("Options:\n");
+	printf("--matrix FILENAME           MatrixMarket file containing the spasre matrix\n");
+	printf("--prime P                   compute modulo P (2 <= P < 2**62; the reference's cap of 2**30-35 is lifted)\n");
+	printf("--n N                       blocking factor [default 1, at most %d]\n", BLZ_MAX_N);
+	printf("--output-file FILENAME      store the block of kernel vectors\n");
+	printf("--right                     compute right kernel vectors\n");
+	printf("--left                      compute left kernel vectors [default]\n");
+	printf("--stop-after N              stop the algorithm after N iterations\n");
+	printf("--checkpoint [cp]           make a checkpoint every cp seconds [default 60] (lanczos_modp.ckpt)\n");
+	printf("--load-checkpoint           restart from the checkpoint in the current directory\n");
+	printf("--device D                  HIP device to run on [default 0]\n");
+	printf("\n");
+	printf("The --matrix and --prime arguments are required\n");
+	printf("The --stop-after and --output-file arguments mutually exclusive\n");
+	exit(0);
+}
+
+static void process_command_line_options(int argc, char **argv)
+{
+	struct option longopts[] = {
+		{"matrix", required_argument, NULL, 'm'}, {"prime", required_argument, NULL, 'p'},
+		{"n", required_argument, NULL, 'n'}, {"output-file", required_argument, NULL, 'o'},
+		{"right", no_argument, NULL, 'r'}, {"left", no_argument, NULL, 'l'},
+		{"stop-after", required_argument, NULL, 's'}, {"checkpoint", optional_argument, NULL, 'c'},
+		{"load-checkpoint", no_argument, NULL, 'L'}, {"device", required_argument, NULL, 'd'},
+		{"help", no_argument, NULL, 'h'}, {NULL, 0, NULL, 0}
+	};
+	int ch;
+	while ((ch = getopt_long(argc, argv, "", longopts, NULL)) != -1) {
+		switch (ch) {
+		case 'm': matrix_filename = optarg; break;
+		case 'n': n = atoi(optarg); break;
+		case 'p': prime = strtoull(optarg, NULL, 10); break;
+		case 'o': kernel_filename = optarg; break;
+		case 'r': right_kernel = true; break;
+		case 'l': right_kernel = false; break;
+		case 's': stop_after = (int)atoll(optarg); break;
+		case 'c':	/* optional, possibly space-separated value: openMP/lanczos_modp.c:225-235 */
+			checkpoints = true;
+			if (optarg == NULL && optind < argc && argv[optind][0] != '-')
+				optarg = argv[optind++];
+			if (optarg)
+				checkpoint_timer = atoi(optarg);
+			break;
+		case 'L': load_checkpoint = true; break;
+		case 'd': device = atoi(optarg); break;
+		case 'h': usage(argv); break;
+		default: errx(1, "Unknown option\n");
+		}
+	}
+	if (matrix_filename == NULL || prime == 0)	/* sequential/lanczos_modp.c:183-187 */
+		usage(argv);
+	if (kernel_filename != NULL && stop_after > 0)
+		usage(argv);
+	if (prime >= (1ull << 62))
+		errx(1, "p is capped at 2**62 - 1.");
+	if (n < 1 || n > BLZ_MAX_N)
+		errx(1, "n must be between 1 and %d", BLZ_MAX_N);
+}
+
+#define CHECK(call)                                                \
+	do {                                                       \
+		if ((call) != BLZ_OK)                              \
+			errx(1, "%s", blz_last_error());           \
+	} while (0)
+
+static int n_iterations, expected_iterations;
+static double start, last_print, extra_time;
+static bool eta_flag;
+
+/* verbosity(), sequential/lanczos_modp.c:494-529 (at most one line per second). */
+static void verbosity(void)
+{
+	const double elapsed = wtime() - start;
+	if (elapsed - last_print < 1)
+		return;
+	last_print = elapsed;
+	const double per_iteration = (elapsed + extra_time) / (n_iterations > 0 ? n_iterations : 1);
+	double estimated_length = expected_iterations * per_iteration;
+	time_t end = (time_t)(start - extra_time + estimated_length);
+	if (!eta_flag) {
+		int d = (int)(estimated_length / 86400);
+		estimated_length -= d * 86400.0;
+		int h = (int)(estimated_length / 3600);
+		estimated_length -= h * 3600.0;
+		int m = (int)(estimated_length / 60);
+		estimated_length -= m * 60.0;
+		printf("    - Expected duration : ");
+		if (d > 0) printf("%d j ", d);
+		if (h > 0) printf("%d h ", h);
+		if (m > 0) printf("%d min ", m);
+		printf("%d s\n", (int)estimated_length);
+		eta_flag = true;
+	}
+	char eta[30];
+	ctime_r(&end, eta);
+	eta[strlen(eta) - 1] = 0;
+	printf("\r    - iteration %d / %d. %.3fs per iteration. ETA: %s", n_iterations, expected_iterations,
+	       per_iteration, eta);
+	fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+	process_command_line_options(argc, argv);
+
+	printf("Loading matrix from %s\n", matrix_filename);
+	fflush(stdout);
+	blz_coo M;
+	const double t_load = wtime();
+	CHECK(blz_mm_load(matrix_filename, prime, &M));
+	fprintf(stderr, "  - [matrix coordinate integer general] %ld x %ld with %ld nz\n", (long)M.nrows, (long)M.ncols,
+		(long)M.nnz);
+	fprintf(stderr, "  - Read in %.2fs\n", wtime() - t_load);
+
+	blz_ctx *ctx;
+	CHECK(blz_create(&ctx, device, prime, (int)n));
+	CHECK(blz_set_matrix(ctx, &M, right_kernel, 0, 1));
+	const int64_t nrows = right_kernel ? M.ncols : M.nrows;
+	const int64_t ncols = right_kernel ? M.nrows : M.ncols;
+	blz_coo_free(&M);
+
+	printf("Block Lanczos\n");
+	const long npad = (long)((nrows + n - 1) / n * n), mpad = (long)((ncols + n - 1) / n * n);
+	const long block_size_pad = (npad > mpad ? npad : mpad) * n;
+	char human[32];
+	human_format(human, 4L * blz_word_bytes(ctx) * block_size_pad);
+	printf("  - Extra storage needed: %sB\n", human);
+	expected_iterations = 1 + (int)(ncols / n);	/* sequential/lanczos_modp.c:610 */
+
+	uint64_t *v = malloc(sizeof(uint64_t) * (size_t)(nrows * n + 1));
+	uint64_t *p = malloc(sizeof(uint64_t) * (size_t)(nrows * n + 1));
+	if (!v || !p)
+		errx(1, "impossible d'allouer les blocs de vecteur");
+	if (load_checkpoint) {
+		int64_t its = 0;
+		if (access("lanczos_modp.ckpt", R_OK) == 0)
+			CHECK(blz_checkpoint_load("lanczos_modp.ckpt", prime, (int)n, right_kernel, nrows, &its, v, p));
+		else
+			CHECK(blz_checkpoint_load_ref_text(".", (int)n, nrows, ncols, &its, v, p));
+		CHECK(blz_init_v(ctx));
+		CHECK(blz_set_block(ctx, BLZ_V, v));
+		CHECK(blz_set_block(ctx, BLZ_P, p));
+		CHECK(blz_set_iterations(ctx, its));
+		n_iterations = (int)its;
+		expected_iterations -= n_iterations;	/* openMP/lanczos_modp.c:971-972 */
+	} else {
+		CHECK(blz_init_v(ctx));
+	}
+	human_format(human, expected_iterations);
+	printf("  - Expecting %s iterations\n", human);
+
+	printf("  - Main loop\n");
+	start = wtime();
+	double checkpoint_start = wtime();
+	int batch = 1, stopped = 0;
+	while (!stopped) {
+		int todo = batch;
+		if (stop_after > 0) {
+			if (n_iterations >= stop_after)
+				break;
+			if (todo > stop_after - n_iterations)
+				todo = stop_after - n_iterations;
+		}
+		int done = 0;
+		float ms = 0;
+		CHECK(blz_iterate(ctx, todo, &done, &stopped, &ms));
+		n_iterations += done;
+		verbosity();
+		/* keep the host out of the loop: grow the batch until one batch takes ~0.25 s */
+		if (ms < 250.0f && batch < 4096)
+			batch *= 2;
+		if (checkpoints && !stopped && (wtime() - checkpoint_start) >= checkpoint_timer) {
+			printf("\n");
+			CHECK(blz_get_block(ctx, BLZ_V, v));
+			CHECK(blz_get_block(ctx, BLZ_P, p));
+			printf("		>> Making a snapshot in lanczos_modp.ckpt (iteration %d)\n", n_iterations);
+			CHECK(blz_checkpoint_save("lanczos_modp.ckpt", prime, (int)n, right_kernel, nrows, n_iterations, v, p));
+			const char *ref = getenv("BLZ_REF_CHECKPOINT");
+			if (ref && ref[0] == '1' && prime < (1ull << 32)) {
+				uint64_t *t = calloc((size_t)(ncols * n + 1), sizeof *t), *a = calloc((size_t)(nrows * n + 1), sizeof *a);
+				CHECK(blz_get_block(ctx, BLZ_TMP, t));
+				CHECK(blz_get_block(ctx, BLZ_AV, a));
+				CHECK(blz_checkpoint_save_ref_text(".", (int)n, nrows, ncols, n_iterations, start, wtime(), v, t, a, p));
+				free(t);
+				free(a);
+			}
+			checkpoint_start = wtime();
+		}
+	}
+	printf("\n");
+
+	if (stop_after < 0) {		/* final_check(), sequential/lanczos_modp.c:560-582 */
+		int nonzero = 0, zero = 0;
+		CHECK(blz_final_check(ctx, &nonzero, &zero));
+		printf("Final check:\n");
+		printf(nonzero ? "  - OK:    v != 0\n" : "  - KO:    v == 0\n");
+		printf(zero ? "  - OK: vt*M == 0\n" : "  - KO: vt*M != 0\n");
+	}
+	printf("  - Terminated in %.1fs after %d iterations\n", wtime() - start, n_iterations);
+
+	if (kernel_filename) {
+		CHECK(blz_get_block(ctx, BLZ_V, v));
+		printf("Saving result in %s\n", kernel_filename);
+		CHECK(blz_save_block(kernel_filename, nrows, (int)n, v));
+	} else {
+		printf("Not saving result (no --output given)\n");
+	}
+	free(v);
+	free(p);
+	blz_destroy(ctx);
+	exit(EXIT_SUCCESS);
+}

@@ -1,0 +1,197 @@
+/*
+ * blz.h -- C ABI of libblz_hip.so: the block-Lanczos-mod-p hot path on MI355X (gfx950).
+ *
+ * The reference (T-amairi/block-lanczos-algorithm-parallelization) has no FFI or plugin seam:
+ * its kernels are plain C functions inside sequential/lanczos_modp.c, parameterised by two
+ * globals (`long n`, `u64 prime`, :39-40) and caller-owned flat arrays.  This header exports one
+ * entry point per reference function on the hot path, with the globals folded into an opaque
+ * per-GPU context.  File:line citations are relative to /root/reference/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no C++ or torch types cross the boundary.
+ *   - every function returns 0 (BLZ_OK) or a negative BLZ_E* code; blz_last_error() holds the
+ *     text the reference would have passed to errx() (thread-local, valid until the next call).
+ *   - host blocks are row-major rows x n arrays of uint64_t canonical residues in [0,p), exactly
+ *     the reference's `v[i*n + l]` layout (sequential/lanczos_modp.c:282-284) with the word
+ *     widened from u32 to u64 (the reference's cap p <= 2^30-35, :189-193, is lifted to p < 2^62).
+ *   - a context owns all device memory and one HIP stream; the caller owns every host pointer.
+ *     One context per GPU, driven by one host thread at a time.
+ *   - functions in the "host-side" section never touch the GPU and work on any machine.
+ */
+#ifndef BLZ_H
+#define BLZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLZ_OK          0
+#define BLZ_EINVAL     -1	/* bad argument / unsupported size */
+#define BLZ_EIO        -2	/* file could not be opened / parsed */
+#define BLZ_EFORMAT    -3	/* MatrixMarket type not "coordinate integer general" */
+#define BLZ_ENOMEM     -4
+#define BLZ_EHIP       -5	/* a HIP runtime call failed */
+#define BLZ_ENOGPU     -6	/* no usable gfx950 device: there is NO CPU fallback */
+#define BLZ_ECOMM      -7	/* RCCL failure */
+
+#define BLZ_MAX_N      64	/* block width limit (one wavefront holds a block row) */
+
+/* block selectors: the four N x n blocks of block_lanczos(), sequential/lanczos_modp.c:602-605 */
+enum { BLZ_V = 0, BLZ_TMP = 1, BLZ_AV = 2, BLZ_P = 3 };
+/* small n x n (or n) operands of one iteration, sequential/lanczos_modp.c:638-643 */
+enum { BLZ_VTAV = 0, BLZ_VTAAV = 1, BLZ_WINV = 2, BLZ_D = 3 };
+
+typedef struct blz_ctx blz_ctx;
+
+const char *blz_last_error(void);
+int blz_version(void);
+
+/* ------------------------------------------------------------------ host-side (no GPU) */
+
+/* struct sparsematrix_t, sequential/lanczos_modp.c:55-62: 0-based COO triplets in file order;
+ * x already canonicalised as the loader does (below). */
+typedef struct {
+	int64_t nrows, ncols, nnz;
+	int32_t *i, *j;
+	uint32_t *x;
+} blz_coo;
+
+/* CSR of M (or of M^T): what the HIP SpMV streams.  row_ptr has rows+1 entries. */
+typedef struct {
+	int64_t rows, cols, nnz;
+	uint32_t *row_ptr;
+	int32_t *col_idx;
+	uint32_t *val;		/* NULL = every entry is 1 (pattern path) */
+} blz_csr;
+
+/* sparsematrix_mm_load(), sequential/lanczos_modp.c:199-263: accepts only
+ * "matrix coordinate integer general" (:216-221, BLZ_EFORMAT otherwise); entries are parsed as
+ * C ints, stored into a u32 and reduced `% prime` (:238-243) -- negative entries therefore wrap
+ * to 2^32-|x| before the reduction, exactly as in the reference and in checker_modp.c:170-175.
+ * Unlike the reference, out-of-range indices are an error (BLZ_EIO) instead of undefined behaviour. */
+int blz_mm_load(const char *path, uint64_t prime, blz_coo *out);
+void blz_coo_free(blz_coo *M);
+
+/* Seeded synthetic stand-in for a SuiteSparse matrix that is not on the box:
+ * row r gets floor(nnz/R) + (r < nnz mod R) distinct uniform columns; values from
+ * {1,1,1,2,3,-1,-2} (pattern=0, canonicalised like the loader does) or all 1 (pattern=1). */
+int blz_synth_coo(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int pattern,
+		  uint64_t prime, blz_coo *out);
+
+/* COO -> CSR of M (transpose=0) or of M^T (transpose=1); duplicates are kept (they add,
+ * as in the reference's scatter loop :277-286).  pattern!=0 drops the value array when all
+ * values are 1. */
+int blz_csr_from_coo(const blz_coo *M, int transpose, int pattern, blz_csr *out);
+void blz_csr_free(blz_csr *A);
+
+/* nnz-balanced contiguous row partition: bounds[0]=0 <= ... <= bounds[parts]=rows. */
+int blz_partition_rows(const blz_csr *A, int parts, int64_t *bounds);
+
+/* rng_state/random64(), sequential/lanczos_modp.c:67-87, and the initialisation
+ * `v[i] = random64() % prime` in row-major order (:624-625). */
+void blz_rng_seed(uint64_t state[4]);
+uint64_t blz_rng_next(uint64_t state[4]);
+int blz_rng_fill(uint64_t *v, int64_t words, uint64_t prime);
+
+/* save_vector_block(), sequential/lanczos_modp.c:673-686: MatrixMarket "array integer general",
+ * the same fixed comment line, column-major "%d" lines (words >= 2^32, which the reference
+ * cannot produce, are written as unsigned decimals). */
+int blz_save_block(const char *path, int64_t nrows, int n, const uint64_t *v);
+
+/* Checkpoints (openMP/lanczos_modp.c:571-676, :933-940, :1013-1022).  blz_checkpoint_save writes
+ * one binary file atomically (tmp + rename): v, p, iteration count, prime, n, shape.
+ * The *_ref_text pair reads/writes the reference's five text files (v.txt tmp.txt Av.txt p.txt
+ * verbosity.txt) in `dir` so that runs can be handed over in either direction (p < 2^32 only). */
+int blz_checkpoint_save(const char *path, uint64_t prime, int n, int right, int64_t nrows,
+			int64_t iterations, const uint64_t *v, const uint64_t *p);
+int blz_checkpoint_load(const char *path, uint64_t prime, int n, int right, int64_t nrows,
+			int64_t *iterations, uint64_t *v, uint64_t *p);
+int blz_checkpoint_save_ref_text(const char *dir, int n, int64_t nrows, int64_t ncols,
+				 int64_t iterations, double start, double now, const uint64_t *v,
+				 const uint64_t *tmp, const uint64_t *Av, const uint64_t *p);
+int blz_checkpoint_load_ref_text(const char *dir, int n, int64_t nrows, int64_t ncols,
+				 int64_t *iterations, uint64_t *v, uint64_t *p);
+
+/* ------------------------------------------------------------------------- device side */
+
+int blz_device_count(void);	/* 0 when no GPU is visible; never fails */
+
+/* Replaces the globals `n` and `prime`.  Fails with BLZ_ENOGPU when there is no device:
+ * the product has no CPU path.  2 <= prime < 2^62, 1 <= n <= BLZ_MAX_N. */
+int blz_create(blz_ctx **out, int device, uint64_t prime, int n);
+void blz_destroy(blz_ctx *ctx);
+int blz_word_bytes(const blz_ctx *ctx);	/* 4 if prime < 2^32 else 8: width of a residue in HBM */
+
+/* Upload M for the solve x*M=0 (right=0) or M*x=0 (right=1), as block_lanczos(M, n, transpose)
+ * receives it (sequential/lanczos_modp.c:585).  Builds CSR(M) and CSR(M^T) on the host, keeps
+ * this rank's nnz-balanced row slabs, allocates the four blocks and zeroes them (:617-622).
+ * rank/nranks = 0/1 for a single GPU. */
+int blz_set_matrix(blz_ctx *ctx, const blz_coo *M, int right, int rank, int nranks);
+
+int64_t blz_rows(const blz_ctx *ctx, int block);	/* global row count of a block (N or C) */
+int64_t blz_local_rows(const blz_ctx *ctx, int block, int64_t *first);	/* this rank's slab */
+
+/* v <- random64() % p for this rank's rows, everything else 0 (:617-625). */
+int blz_init_v(blz_ctx *ctx);
+
+/* Copy a whole block (global rows x n) host->device / device->host.  With nranks > 1 set_block
+ * keeps the local slab (V, TMP additionally the gathered copy); get_block returns the local slab
+ * in place of its global rows and leaves the rest of `host` untouched. */
+int blz_set_block(blz_ctx *ctx, int block, const uint64_t *host);
+int blz_get_block(blz_ctx *ctx, int block, uint64_t *host);
+int blz_set_small(blz_ctx *ctx, int which, const uint64_t *host);
+int blz_get_small(blz_ctx *ctx, int which, uint64_t *host);
+
+/* sparse_matrix_vector_product(y, M, x, transpose), sequential/lanczos_modp.c:266-287:
+ * dst = M*src (transpose=0) or M^T*src (transpose=1), all n columns, canonical residues. */
+int blz_spmv(blz_ctx *ctx, int transpose, int src_block, int dst_block);
+
+/* block_dot_products(), :443-453: vtAv = v^T*Av, vtAAv = Av^T*Av (kept on the device;
+ * copied to the host arrays when they are not NULL).  With nranks > 1 the partial products are
+ * summed over ranks (RCCL all-reduce of 2*n*n words). */
+int blz_block_dot(blz_ctx *ctx, uint64_t *vtAv, uint64_t *vtAAv);
+
+/* semi_inverse(vtAv, winv, d), :342-438, on the device copy of vtAv (set it with blz_set_small
+ * or blz_block_dot).  Same pivot order, hence the same d and winv. */
+int blz_semi_inverse(blz_ctx *ctx, int *npiv, uint64_t *winv, uint64_t *d);
+
+/* orthogonalize(), :456-492, followed by the copy v <- tmp of :655-656 (done in place). */
+int blz_orthogonalize(blz_ctx *ctx);
+
+/* The loop body of block_lanczos(), :631-659, up to max_iters times without host round trips.
+ * *done = iterations completed (the reference's n_iterations increments), *stopped = 1 once
+ * semi_inverse returned 0 (:644-650); later calls are then no-ops.  *ms (optional) = device time
+ * of this call measured with HIP events on the context's stream. */
+int blz_iterate(blz_ctx *ctx, int max_iters, int *done, int *stopped, float *ms);
+int64_t blz_iterations(const blz_ctx *ctx);
+int blz_set_iterations(blz_ctx *ctx, int64_t iterations);	/* --load-checkpoint */
+
+/* final_check(), :560-582, on V and on TMP (= M^T v of the last iteration). */
+int blz_final_check(blz_ctx *ctx, int *v_nonzero, int *vtm_zero);
+
+/* Measurement: run one hot-path kernel `reps` times between two HIP events on the context's
+ * stream and return the mean time.  which: 0 = first SpMV of an iteration (:635), 1 = second
+ * (:636), 2 = block_dot, 3 = orthogonalize (on scratch copies), 4 = whole iteration. */
+int blz_time_kernel(blz_ctx *ctx, int which, int reps, float *ms_mean);
+int blz_sync(blz_ctx *ctx);
+
+/* Per-kernel HIP-event spans inside blz_iterate (on the stream the kernels run on).  blz_profile(ctx,1)
+ * clears and starts collecting, blz_profile(ctx,0) stops; blz_profile_read sums the spans collected so
+ * far into 8 classes: 0 first SpMV, 1 second SpMV, 2 block_dot (+finalize), 3 semi_inverse,
+ * 4 orthogonalize, 5 all-gather of v, 6 all-gather of tmp, 7 all-reduce of the n x n products. */
+#define BLZ_PROFILE_CLASSES 8
+int blz_profile(blz_ctx *ctx, int enable);
+int blz_profile_read(blz_ctx *ctx, double ms_sum[BLZ_PROFILE_CLASSES], int64_t launches[BLZ_PROFILE_CLASSES]);
+
+/* Multi-GPU (one process per GPU).  id_bytes = ncclUniqueId from blz_comm_unique_id() on rank 0,
+ * broadcast by the caller (bench.py uses torch.distributed for that and nothing else). */
+int blz_comm_unique_id(void *id_out, size_t id_bytes);	/* needs id_bytes >= 128 */
+int blz_comm_init(blz_ctx *ctx, const void *id, size_t id_bytes, int rank, int nranks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

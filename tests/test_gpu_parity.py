@@ -1,0 +1,202 @@
+"""GPU parity: every hot-path entry point of libblz_hip.so, called through the C ABI, against
+(a) golden vectors produced by the reference itself and (b) the CPU oracle on the same seeded inputs.
+Integer path => bit-exact equality everywhere (no tolerances).
+"""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import blz
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MATRIX_OF = {"tref": "trefethen20", "r300": "rand300x200", "wide": "wide120x260",
+             "quirks": "quirks40x30", "r3000": "rand3000x2000"}
+TRAJ = sorted(glob.glob(os.path.join(GOLDEN, "traj_*.npz")))
+KERN = sorted(glob.glob(os.path.join(GOLDEN, "kern_*.npz")))
+P61 = (1 << 61) - 1
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()
+
+
+def load_both(name, prime):
+    path = os.path.join(GOLDEN, name + ".mtx")
+    return blz.Matrix.load(path, prime), orc.Matrix.load(path, prime)
+
+
+def as_orc(M):
+    return orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+
+
+@pytest.mark.parametrize("path", KERN, ids=[os.path.basename(p)[5:-4] for p in KERN])
+def test_each_kernel_against_reference_vectors(path):
+    g = np.load(path)
+    p, n, right = int(g["prime"]), int(g["n"]), bool(g["right"])
+    M, _ = load_both(MATRIX_OF[os.path.basename(path).split("_")[1]], p)
+    with blz.Context(p, n) as ctx:
+        ctx.set_matrix(M, right)
+        assert ctx.word_bytes == (4 if p < 2 ** 32 else 8)
+        for it in sorted({k.split("_")[0] for k in g.files if k.startswith("it")}):
+            v, tmp, Av, pb = (g[f"{it}_{k}"] for k in ("v", "tmp", "Av", "p"))
+            ctx.set_block(blz.V, v)
+            ctx.set_block(blz.P, pb)
+            ctx.spmv(not right, blz.V, blz.TMP)             # sequential/lanczos_modp.c:635
+            assert np.array_equal(ctx.get_block(blz.TMP), tmp)
+            ctx.spmv(right, blz.TMP, blz.AV)                # :636
+            assert np.array_equal(ctx.get_block(blz.AV), Av)
+            a, b = ctx.block_dot()                          # :640
+            assert np.array_equal(a, g[f"{it}_vtAv"]) and np.array_equal(b, g[f"{it}_vtAAv"])
+            npiv, winv, d = ctx.semi_inverse()              # :644
+            assert np.array_equal(winv, g[f"{it}_winv"]) and np.array_equal(d, g[f"{it}_d"])
+            assert npiv == int(d.sum())
+            ctx.orthogonalize()                             # :652-656
+            assert np.array_equal(ctx.get_block(blz.V), g[f"{it}_vnext"])
+            assert np.array_equal(ctx.get_block(blz.P), g[f"{it}_pnext"])
+
+
+def test_semi_inverse_against_reference_vectors():
+    g = np.load(os.path.join(GOLDEN, "semi_inverse.npz"))
+    for key in sorted(k[:-2] for k in g.files if k.endswith("_M")):
+        n, p = int(key.split("_")[0][1:]), int(key.split("_")[1][1:])
+        with blz.Context(p, n) as ctx:
+            for M, winv, d, npiv in zip(g[key + "_M"], g[key + "_winv"], g[key + "_d"], g[key + "_npiv"]):
+                ctx.set_small(blz.VTAV, M)
+                got = ctx.semi_inverse()
+                assert got[0] == npiv and np.array_equal(got[1], winv) and np.array_equal(got[2], d), key
+
+
+@pytest.mark.parametrize("path", TRAJ, ids=[os.path.basename(p)[5:-4] for p in TRAJ])
+def test_trajectory_against_reference(path):
+    """Iteration by iteration: the n x n operands, the pivot sets and sha256(v) of the reference run."""
+    g = np.load(path)
+    p, n, right, stop = int(g["prime"]), int(g["n"]), bool(g["right"]), int(g["stop_after"])
+    M, _ = load_both(MATRIX_OF[os.path.basename(path).split("_")[1]], p)
+    step_checks = len(g["npiv"]) <= 80
+    with blz.Context(p, n) as ctx:
+        ctx.set_matrix(M, right)
+        ctx.init_v()
+        assert np.array_equal(ctx.get_block(blz.V), g["v0"])
+        if step_checks:
+            for k in range(len(g["npiv"])):
+                if stop > 0 and k == stop:
+                    break
+                assert sha(ctx.get_block(blz.V)) == str(g["vhash"][k])
+                done, stopped, _ = ctx.iterate(1)
+                for which, name in ((blz.VTAV, "vtAv"), (blz.VTAAV, "vtAAv"), (blz.WINV, "winv"), (blz.D, "d")):
+                    assert np.array_equal(ctx.get_small(which), g[name][k]), (name, k)
+                assert stopped == (g["npiv"][k] == 0) and done == (0 if stopped else 1)
+        else:
+            while True:
+                todo = 64 if stop <= 0 else min(64, stop - ctx.iterations)
+                if todo <= 0:
+                    break
+                _, stopped, _ = ctx.iterate(todo)
+                if stopped:
+                    break
+        assert ctx.iterations == int(g["iterations"])
+        assert np.array_equal(ctx.get_block(blz.V), g["final_v"])
+        if stop <= 0:
+            assert np.array_equal(ctx.get_block(blz.TMP), g["final_tmp"])
+            nz, zero = ctx.final_check()
+            assert nz == bool(g["final_v"].any()) and zero == (not g["final_tmp"].any())
+        # a stopped context stays put (later calls are no-ops)
+        if stop <= 0:
+            before = ctx.get_block(blz.V)
+            assert ctx.iterate(3)[:2] == (0, True) and np.array_equal(ctx.get_block(blz.V), before)
+
+
+@pytest.mark.parametrize("p", [P61, 4294967311, (1 << 62) - 57, 2305843009213693907, 2147483647, 65537, 7, 2])
+@pytest.mark.parametrize("name,n,right", [("quirks40x30", 2, False), ("wide120x260", 4, True), ("rand300x200", 8, False)])
+def test_full_solve_against_oracle_all_prime_classes(p, name, n, right):
+    """Mersenne-61, Mersenne-31, Barrett 32/33/61/62-bit and tiny primes; oracle = same code path that the
+    golden tests pin to the reference."""
+    M, Mo = load_both(name, p)
+    want = orc.block_lanczos(Mo, n, p, right=right)
+    got = blz.solve(M, p, n, right=right, batch=7)
+    assert got["iterations"] == want["iterations"]
+    assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["tmp"], want["tmp"])
+    assert np.array_equal(got["p"], want["p"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 8, 11, 16, 24, 32, 64])
+def test_every_block_width(n):
+    p = P61 if n % 2 else 1073741789
+    M, Mo = load_both("rand300x200", p)
+    its = 6 if n <= 32 else 3        # rank(M M^T) <= 200: wider blocks exhaust the Krylov space earlier
+    want = orc.block_lanczos(Mo, n, p, stop_after=its)
+    got = blz.solve(M, p, n, stop_after=its, batch=4)
+    assert got["iterations"] == want["iterations"] == its
+    assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
+
+
+def test_n_out_of_range_and_bad_prime_are_errors():
+    for (p, n) in ((65537, 0), (65537, 65), (1, 4), (0, 4), (1 << 62, 4)):
+        with pytest.raises(blz.BlzError) as e:
+            blz.Context(p, n)
+        assert e.value.code == blz.EINVAL
+
+
+def test_degenerate_matrices():
+    p, n = P61, 4
+    # no entries at all: v^T A v = 0 -> stops at once, v stays the random block, tmp = 0
+    Z = blz.Matrix(30, 20, [], [], [])
+    got = blz.solve(Z, p, n)
+    want = orc.block_lanczos(as_orc(Z), n, p)
+    assert got["iterations"] == want["iterations"] == 0 and np.array_equal(got["v"], want["v"])
+    assert got["final_check"] == (True, True)
+    # a single row / single column
+    for (nr, nc) in ((1, 9), (9, 1)):
+        A = blz.Matrix(nr, nc, [0] * 3 if nr == 1 else [0, 4, 8], [0, 4, 8] if nr == 1 else [0] * 3, [1, 2, 5])
+        for right in (False, True):
+            got = blz.solve(A, p, 2, right=right)
+            want = orc.block_lanczos(as_orc(A), 2, p, right=right)
+            assert got["iterations"] == want["iterations"] and np.array_equal(got["v"], want["v"])
+
+
+@pytest.mark.parametrize("shape,nnz,n,p,right,pattern", [
+    ((40000, 1500, 160000), None, 4, 2147483647, False, False),   # relat8-like aspect, config 2 arithmetic
+    ((60000, 2700, 190000), None, 8, P61, True, False),           # relat9-like aspect, config 3 arithmetic
+    ((20000, 20500, 390000), None, 8, P61, False, False),         # GL7d19-like density (19.5 / row), config 4
+    ((30000, 30000, 1200000), None, 16, P61, False, True),        # config 5: all-ones pattern, 40 / row
+])
+def test_synthetic_config_shapes_against_oracle(shape, nnz, n, p, right, pattern):
+    nr, nc, nz = shape
+    M = blz.Matrix.synth(nr, nc, nz, 0x474C3764, p, pattern=pattern)
+    Mo = as_orc(M)
+    its = 5
+    want = orc.block_lanczos(Mo, n, p, right=right, stop_after=its)
+    got = blz.solve(M, p, n, right=right, stop_after=its, batch=2)
+    assert got["iterations"] == its
+    assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
+
+
+def test_heavy_rows_do_not_overflow():
+    """openMP/lanczos_modp.c:352-365 overflows its u64 sums on long rows of large values;
+    the 128-bit accumulators here must not: one row of 5000 entries, all 2^32-1, p just below 2^62."""
+    p, n = (1 << 62) - 57, 4
+    nc = 6000
+    i = np.zeros(5000, dtype=np.int32)
+    j = np.arange(5000, dtype=np.int32)
+    x = np.full(5000, 2 ** 32 - 1, dtype=np.uint32)
+    i = np.concatenate([i, np.arange(1, 50, dtype=np.int32)])
+    j = np.concatenate([j, np.arange(5000, 5049, dtype=np.int32)])
+    x = np.concatenate([x, np.full(49, 3, dtype=np.uint32)])
+    M = blz.Matrix(50, nc, i, j, x)
+    with blz.Context(p, n) as ctx:
+        ctx.set_matrix(M, False)
+        xin = np.full(nc * n, p - 1, dtype=np.uint64)
+        ctx.set_block(blz.TMP, xin)
+        ctx.spmv(False, blz.TMP, blz.AV)
+        assert np.array_equal(ctx.get_block(blz.AV), orc.spmv(as_orc(M), xin, False, n, p))
+        vin = np.full(50 * n, p - 2, dtype=np.uint64)
+        ctx.set_block(blz.V, vin)
+        ctx.spmv(True, blz.V, blz.TMP)
+        assert np.array_equal(ctx.get_block(blz.TMP), orc.spmv(as_orc(M), vin, True, n, p))

@@ -1,0 +1,140 @@
+"""CPU-side checks of libblz_hip.so: it loads, exports every symbol include/blz.h declares, and its
+plain-C host half (ingest, CSR build, partition, RNG, writer, checkpoints) matches the reference
+fixtures.  No compute call is made here -- those need a GPU and live in test_gpu_parity.py.
+"""
+import glob
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import blz
+import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MATRIX_OF = {"tref": "trefethen20", "r300": "rand300x200", "wide": "wide120x260",
+             "quirks": "quirks40x30", "r3000": "rand3000x2000"}
+TRAJ = sorted(glob.glob(os.path.join(GOLDEN, "traj_*.npz")))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "blz.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(blz_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 30
+    L = blz.lib()
+    missing = [nm for nm in names if not hasattr(L, nm)]
+    assert not missing, missing
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if blz.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(blz.BlzError) as e:
+        blz.Context(65537, 4)
+    assert e.value.code == blz.ENOGPU
+
+
+def test_rng_matches_reference():
+    g = json.load(open(os.path.join(GOLDEN, "rng.json")))
+    assert blz.rng_draws(len(g["draws"])) == g["draws"]
+
+
+@pytest.mark.parametrize("path", TRAJ, ids=[os.path.basename(p)[5:-4] for p in TRAJ])
+def test_loader_and_init_match_reference(path):
+    g = np.load(path)
+    name = MATRIX_OF[os.path.basename(path).split("_")[1]]
+    p = int(g["prime"])
+    M = blz.Matrix.load(os.path.join(GOLDEN, name + ".mtx"), p)
+    assert np.array_equal(M.i, g["coo_i"]) and np.array_equal(M.j, g["coo_j"]) and np.array_equal(M.x, g["coo_x"])
+    assert np.array_equal(blz.rng_fill(len(g["v0"]), p), g["v0"])
+
+
+def test_loader_rejects_what_reference_rejects(tmp_path):
+    bad = tmp_path / "m.mtx"
+    for banner in ("%%MatrixMarket matrix coordinate integer symmetric", "%%MatrixMarket matrix coordinate real general",
+                   "%%MatrixMarket matrix array integer general", "%%MatrixMarket matrix coordinate pattern general"):
+        bad.write_text(banner + "\n2 2 1\n1 1 1\n")
+        with pytest.raises(blz.BlzError) as e:
+            blz.Matrix.load(str(bad), 65537)
+        assert e.value.code == blz.EFORMAT
+    bad.write_text("%%MatrixMarket matrix coordinate integer general\n% c\n2 2 2\n1 1 1\n")
+    with pytest.raises(blz.BlzError) as e:
+        blz.Matrix.load(str(bad), 65537)
+    assert e.value.code == blz.EIO and "parse error entry 1" in str(e.value)
+    bad.write_text("%%MatrixMarket matrix coordinate integer general\n2 2 1\n3 1 1\n")
+    with pytest.raises(blz.BlzError):
+        blz.Matrix.load(str(bad), 65537)
+    with pytest.raises(blz.BlzError):
+        blz.Matrix.load(str(tmp_path / "absent.mtx"), 65537)
+    # accepted oddities: mixed-case banner, comments, blank-separated entries on one line, empty matrix
+    bad.write_text("%%MatrixMarket MATRIX Coordinate Integer GENERAL\n%x\n%y\n3 2 2\n1 1 -1   3 2 7\n")
+    M = blz.Matrix.load(str(bad), 65537)
+    assert (M.nrows, M.ncols, M.nnz) == (3, 2, 2) and list(M.x) == [(2 ** 32 - 1) % 65537, 7]
+    bad.write_text("%%MatrixMarket matrix coordinate integer general\n4 5 0\n")
+    assert blz.Matrix.load(str(bad), 7).nnz == 0
+
+
+@pytest.mark.parametrize("name", ["rand300x200", "quirks40x30", "wide120x260"])
+def test_csr_is_the_same_matrix(name):
+    p = 1073741789
+    M = blz.Matrix.load(os.path.join(GOLDEN, name + ".mtx"), p)
+    for transpose in (False, True):
+        A = M.csr(transpose, pattern=False)
+        rows = M.ncols if transpose else M.nrows
+        assert A["rows"] == rows and A["nnz"] == M.nnz and A["row_ptr"][0] == 0 and A["row_ptr"][-1] == M.nnz
+        ri = np.repeat(np.arange(rows), np.diff(A["row_ptr"].astype(np.int64)))
+        got = sorted(zip(ri.tolist(), A["col_idx"].tolist(), A["val"].tolist()))
+        want = sorted(zip((M.j if transpose else M.i).tolist(), (M.i if transpose else M.j).tolist(), M.x.tolist()))
+        assert got == want  # duplicates kept
+        for parts, b in A["partition"].items():
+            assert b[0] == 0 and b[-1] == rows and all(x <= y for x, y in zip(b, b[1:])) and len(b) == parts + 1
+            w = [int(A["row_ptr"][b[k + 1]]) - int(A["row_ptr"][b[k]]) + b[k + 1] - b[k] for k in range(parts)]
+            assert max(w) <= (M.nnz + rows) / parts + np.diff(A["row_ptr"].astype(np.int64)).max() + 1
+
+
+def test_synthetic_generator_shape_and_determinism():
+    p = (1 << 61) - 1
+    A = blz.Matrix.synth(1000, 700, 5300, 0x52454C38, p)
+    B = blz.Matrix.synth(1000, 700, 5300, 0x52454C38, p)
+    assert np.array_equal(A.i, B.i) and np.array_equal(A.j, B.j) and np.array_equal(A.x, B.x)
+    cnt = np.bincount(A.i, minlength=1000)
+    assert cnt.min() == 5 and cnt.max() == 6 and (cnt[:300] == 6).all() and (cnt[300:] == 5).all()
+    for r in (0, 1, 299, 300, 999):
+        cols = A.j[A.i == r]
+        assert len(set(cols.tolist())) == len(cols) and cols.min() >= 0 and cols.max() < 700
+    assert set(A.x.tolist()) <= {1, 2, 3, 2 ** 32 - 1, 2 ** 32 - 2}  # -1, -2 wrap like the loader's "%d into u32"
+    Cp = blz.Matrix.synth(1000, 700, 5300, 1, p, pattern=True)
+    assert (Cp.x == 1).all() and Cp.csr(False, pattern=True)["val"] is None
+    assert blz.Matrix.synth(1000, 700, 5300, 2, 65537).x.max() < 65537
+
+
+def test_writer_is_byte_identical_to_reference(tmp_path):
+    cli = json.load(open(os.path.join(GOLDEN, "cli.json")))
+    cli.pop("_validation")
+    for tag, c in cli.items():
+        M = orc.Matrix.load(os.path.join(GOLDEN, c["matrix"] + ".mtx"), c["prime"])
+        res = orc.block_lanczos(M, c["n"], c["prime"], right=c["right"])
+        out = str(tmp_path / (tag + ".mtx"))
+        blz.save_block(out, M.ncols if c["right"] else M.nrows, c["n"], res["v"])
+        assert hashlib.sha256(open(out, "rb").read()).hexdigest() == c["out_sha256"]
+
+
+def test_checkpoint_roundtrip_and_mismatch(tmp_path):
+    p, n, nrows = (1 << 61) - 1, 4, 50
+    rng = np.random.default_rng(3)
+    v = rng.integers(0, p, nrows * n, dtype=np.uint64)
+    q = rng.integers(0, p, nrows * n, dtype=np.uint64)
+    path = str(tmp_path / "ck.blz")
+    blz.checkpoint_save(path, p, n, False, nrows, 17, v, q)
+    its, v2, q2 = blz.checkpoint_load(path, p, n, False, nrows)
+    assert its == 17 and np.array_equal(v, v2) and np.array_equal(q, q2)
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]  # atomic rename left no temp file
+    with pytest.raises(blz.BlzError):
+        blz.checkpoint_load(path, p, n, True, nrows)
+    with pytest.raises(blz.BlzError):
+        blz.checkpoint_load(path, 65537, n, False, nrows)
