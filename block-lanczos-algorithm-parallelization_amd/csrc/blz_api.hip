@@ -193,7 +193,7 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	HIPCHK(hipEventCreate(&c->ev1));
 	HIPCHK(hipMalloc(&c->small, small_words(n) * sizeof(u64)));
 	HIPCHK(hipMemset(c->small, 0, small_words(n) * sizeof(u64)));
-	c->max_dot_blocks = c->cfg.num_cu * 2;
+	c->max_dot_blocks = c->cfg.num_cu * 4;
 	HIPCHK(hipMalloc(&c->partial, (size_t)c->max_dot_blocks * 2 * n * n * sizeof(u64)));
 	HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));

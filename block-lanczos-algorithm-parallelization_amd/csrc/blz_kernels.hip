@@ -191,59 +191,169 @@ k_block_dot(const W *__restrict__ V, const W *__restrict__ AV, long long rows, l
 	}
 }
 
-template <typename W, int MERS>
-static hipError_t dot_dispatch(const KernelCfg &c, const W *V, const W *AV, int64_t rows, u64 *partial, int blocks,
-			       long long rpb, const DevCtl *ctl, hipStream_t s)
+/* 64-bit cross-lane read (absolute lane of the wave) */
+MODP_DEV u64 shfl64(u64 x, int src)
 {
-	const int pairs = c.n * c.n;
+	const u32 lo = (u32)__shfl((int)(u32)x, src, 64), hi = (u32)__shfl((int)(u32)(x >> 32), src, 64);
+	return ((u64)hi << 32) | lo;
+}
+
+MODP_DEV u64 shfl_xor64(u64 x, int mask)
+{
+	const u32 lo = (u32)__shfl_xor((int)(u32)x, mask, 64), hi = (u32)__shfl_xor((int)(u32)(x >> 32), mask, 64);
+	return ((u64)hi << 32) | lo;
+}
+
+/*
+ * Fast path for n = NT in {1,2,4,8,16}: a group of NT lanes owns one block row, lane i holds
+ * v[r,i] and Av[r,i] (two fully coalesced loads per row), and the operands Av[r,(i+t) mod NT] arrive
+ * by rotation inside the group.  Lane i accumulates
+ *     vtAv [i][(i+t)%NT]  for t = 0..NT-1
+ *     vtAAv[i][(i+t)%NT]  for t = 0..NT/2   (Av^T Av is symmetric for ANY input, so half is enough)
+ * in 128-bit registers, reduced every m.chunk rows.
+ */
+template <typename W, int MERS, int NT>
+__global__ void __launch_bounds__(BLOCK)
+k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long rows, ModP m,
+		 u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int GPB = BLOCK / NT, H = NT / 2 + 1, SLOTS = NT + H, WAVES = BLOCK / 64;
+	__shared__ u64 red[WAVES][SLOTS][NT];
+	const int t = threadIdx.x, lane = t & 63, i = t & (NT - 1), gbase = lane - i;
+	const long long g0 = (long long)blockIdx.x * GPB + t / NT, ng = (long long)gridDim.x * GPB;
+	Acc a1[NT], a2[H];
+#pragma unroll
+	for (int q = 0; q < NT; q++)
+		acc_zero(a1[q]);
+#pragma unroll
+	for (int q = 0; q < H; q++)
+		acc_zero(a2[q]);
+	u32 cnt = 0;
+	for (long long r = g0; r < rows; r += ng) {
+		const u64 vi = V[(size_t)r * NT + i], ai = AV[(size_t)r * NT + i];
+#pragma unroll
+		for (int q = 0; q < NT; q++) {
+			const u64 aq = q == 0 ? ai : shfl64(ai, gbase + ((i + q) & (NT - 1)));
+			acc_mac64(a1[q], vi, aq);
+			if (q < H)
+				acc_mac64(a2[q], ai, aq);
+		}
+		if (++cnt == m.chunk) {
+			cnt = 0;
+#pragma unroll
+			for (int q = 0; q < NT; q++)
+				acc_set(a1[q], acc_reduce<MERS>(a1[q], m));
+#pragma unroll
+			for (int q = 0; q < H; q++)
+				acc_set(a2[q], acc_reduce<MERS>(a2[q], m));
+		}
+	}
+	/* wave: sum the 64/NT groups; block: sum the waves through LDS */
+#pragma unroll
+	for (int q = 0; q < SLOTS; q++) {
+		u64 x = q < NT ? acc_reduce<MERS>(a1[q < NT ? q : 0], m) : acc_reduce<MERS>(a2[q < NT ? 0 : q - NT], m);
+#pragma unroll
+		for (int off = NT; off < 64; off <<= 1)
+			x = addmod(x, shfl_xor64(x, off), m.p);
+		if (lane < NT)
+			red[t >> 6][q][i] = x;
+	}
+	__syncthreads();
+	for (int e = t; e < SLOTS * NT; e += BLOCK) {
+		const int q = e / NT, ii = e % NT;
+		u64 x = 0;
+#pragma unroll
+		for (int w = 0; w < WAVES; w++)
+			x = addmod(x, red[w][q][ii], m.p);
+		u64 *out = partial + (size_t)blockIdx.x * 2 * NT * NT;
+		if (q < NT) {
+			out[ii * NT + ((ii + q) & (NT - 1))] = x;
+		} else {
+			const int jj = (ii + (q - NT)) & (NT - 1);
+			out[NT * NT + ii * NT + jj] = x;
+			out[NT * NT + jj * NT + ii] = x;
+		}
+	}
+}
+
+template <typename W, int MERS>
+static hipError_t dot_dispatch(const KernelCfg &c, const W *V, const W *AV, int64_t rows, u64 *partial, int max_blocks,
+			       int *nblocks, const DevCtl *ctl, hipStream_t s)
+{
+	const int n = c.n, pairs = n * n;
+	if (n == 1 || n == 2 || n == 4 || n == 8 || n == 16) {
+		const long long gpb = BLOCK / n;
+		long long blocks = (rows + gpb * 8 - 1) / (gpb * 8);	/* >= 8 rows per group */
+		blocks = blocks < 1 ? 1 : (blocks > max_blocks ? max_blocks : blocks);
+		*nblocks = (int)blocks;
+#define DOT_FAST(NN)                                                                                              \
+	case NN:                                                                                                  \
+		hipLaunchKernelGGL((k_block_dot_fast<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, \
+				   (long long)rows, c.m, partial, ctl);                                            \
+		break;
+		switch (n) {
+			DOT_FAST(1)
+			DOT_FAST(2)
+			DOT_FAST(4)
+			DOT_FAST(8)
+			DOT_FAST(16)
+		}
+#undef DOT_FAST
+		return hipGetLastError();
+	}
+	long long blocks = (rows + 255) / 256;
+	blocks = blocks < 1 ? 1 : (blocks > max_blocks ? max_blocks : blocks);
+	const long long rpb = (rows + blocks - 1) / blocks;
+	*nblocks = (int)blocks;
 	if (pairs <= BLOCK)
-		hipLaunchKernelGGL((k_block_dot<W, MERS, 1>), dim3(blocks), dim3(BLOCK), 0, s, V, AV, (long long)rows, rpb,
-				   c.n, c.m, partial, ctl);
+		hipLaunchKernelGGL((k_block_dot<W, MERS, 1>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, (long long)rows,
+				   rpb, n, c.m, partial, ctl);
 	else if (pairs <= 4 * BLOCK)
-		hipLaunchKernelGGL((k_block_dot<W, MERS, 4>), dim3(blocks), dim3(BLOCK), 0, s, V, AV, (long long)rows, rpb,
-				   c.n, c.m, partial, ctl);
+		hipLaunchKernelGGL((k_block_dot<W, MERS, 4>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, (long long)rows,
+				   rpb, n, c.m, partial, ctl);
 	else
-		hipLaunchKernelGGL((k_block_dot<W, MERS, 16>), dim3(blocks), dim3(BLOCK), 0, s, V, AV, (long long)rows, rpb,
-				   c.n, c.m, partial, ctl);
+		hipLaunchKernelGGL((k_block_dot<W, MERS, 16>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, (long long)rows,
+				   rpb, n, c.m, partial, ctl);
 	return hipGetLastError();
 }
 
 hipError_t launch_block_dot(const KernelCfg &c, const void *V, const void *AV, int64_t rows, u64 *partial,
 			    int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
 {
-	long long blocks = (rows + 511) / 512;
-	if (blocks > max_blocks)
-		blocks = max_blocks;
-	if (blocks < 1)
-		blocks = 1;
-	const long long rpb = (rows + blocks - 1) / blocks;
-	*nblocks = (int)blocks;
 	if (c.word == 4)
-		return c.mers == 31 ? dot_dispatch<u32, 31>(c, (const u32 *)V, (const u32 *)AV, rows, partial, (int)blocks, rpb, ctl, s)
-				    : dot_dispatch<u32, 0>(c, (const u32 *)V, (const u32 *)AV, rows, partial, (int)blocks, rpb, ctl, s);
-	return c.mers == 61 ? dot_dispatch<u64, 61>(c, (const u64 *)V, (const u64 *)AV, rows, partial, (int)blocks, rpb, ctl, s)
-			    : dot_dispatch<u64, 0>(c, (const u64 *)V, (const u64 *)AV, rows, partial, (int)blocks, rpb, ctl, s);
+		return c.mers == 31 ? dot_dispatch<u32, 31>(c, (const u32 *)V, (const u32 *)AV, rows, partial, max_blocks, nblocks, ctl, s)
+				    : dot_dispatch<u32, 0>(c, (const u32 *)V, (const u32 *)AV, rows, partial, max_blocks, nblocks, ctl, s);
+	return c.mers == 61 ? dot_dispatch<u64, 61>(c, (const u64 *)V, (const u64 *)AV, rows, partial, max_blocks, nblocks, ctl, s)
+			    : dot_dispatch<u64, 0>(c, (const u64 *)V, (const u64 *)AV, rows, partial, max_blocks, nblocks, ctl, s);
 }
 
+/* out[e] = sum_b partial[b][e] mod p: one wavefront per output word. */
 __global__ void __launch_bounds__(BLOCK)
 k_dot_finalize(const u64 *__restrict__ partial, int nblocks, int words, u64 p, u64 *__restrict__ out,
 	       const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
-	for (int e = blockIdx.x * BLOCK + threadIdx.x; e < words; e += gridDim.x * BLOCK) {
-		u64 s = 0;
-		for (int b = 0; b < nblocks; b++)
-			s = addmod(s, partial[(size_t)b * words + e], p);
+	const int e = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+	if (e >= words)
+		return;
+	u64 s = 0;
+	for (int b = lane; b < nblocks; b += 64)
+		s = addmod(s, partial[(size_t)b * words + e], p);
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		s = addmod(s, shfl_xor64(s, off), p);
+	if (lane == 0)
 		out[e] = s;
-	}
 }
 
 hipError_t launch_dot_finalize(const KernelCfg &c, const u64 *partial, int nblocks, u64 *out, const DevCtl *ctl,
 			       hipStream_t s)
 {
 	const int words = 2 * c.n * c.n;
-	const int blocks = (words + BLOCK - 1) / BLOCK;
+	const int blocks = (words * 64 + BLOCK - 1) / BLOCK;
 	hipLaunchKernelGGL(k_dot_finalize, dim3(blocks), dim3(BLOCK), 0, s, partial, nblocks, words, c.m.p, out, ctl);
 	return hipGetLastError();
 }
@@ -269,58 +379,84 @@ __device__ static u64 dev_invmod(u64 a, u64 p)
 }
 
 /*
- * One Gauss-Jordan sweep, lanes = columns.  Pivot rule of sequential/lanczos_modp.c:351-381 and
- * :393-436: first non-zero entry of column j in rows j..n-1; a column without one is skipped (row j
- * is then never used as a pivot row later); scale, swap into row j, eliminate.  Returns the pivot
- * count; *mask gets bit j for every pivot column.  All control flow is wave-uniform.
+ * One Gauss-Jordan sweep with the pivot rule of sequential/lanczos_modp.c:351-381 / :393-436: for column
+ * j take the first non-zero entry in rows j..n-1; a column without one is skipped (row j is then never
+ * used as a pivot row); swap the pivot row into row j; eliminate column j everywhere else.
+ *
+ * The reference scales each pivot row by the inverse of its pivot (one invmod per pivot, and the
+ * extended Euclid is by far the slowest thing in this kernel).  Here the sweep is FRACTION-FREE: every
+ * row is carried as s_i * (the reference's row) with a non-zero scalar s_i,
+ *     pivot row:   s_j  <- its entry in column j              (instead of dividing the row by it)
+ *     other rows:  row_i <- s_j*row_i - row_i[j]*row_j ,  s_i <- s_i*s_j     (only when row_i[j] != 0)
+ * Zero patterns are unchanged (p prime: no zero divisors), so the pivot choices -- hence d -- are the
+ * reference's, and dividing row i by s_i at the end gives exactly the reference's rows.  The n scalars
+ * are inverted together with ONE invmod (prefix products).  lanes = (row-in-pass, column).
  */
 template <int MERS>
-__device__ static int gauss_sweep(u64 *A, u64 *Wm, int n, const ModP &m, u64 *mask)
+__device__ static int ff_sweep(u64 *A, u64 *Wm, u64 *S, int n, int G, const ModP &m, u64 *mask)
 {
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x, li = lane / G, k = lane % G, RP = 64 / G;
 	int found = 0;
 	u64 bits = 0;
 	for (int j = 0; j < n; j++) {
 		__syncthreads();
-		int piv = -1;
-		for (int i = j; i < n; i++)
-			if (A[i * n + j] != 0) {
-				piv = i;
-				break;
-			}
-		if (piv < 0)
+		const u64 probe = (lane < n && lane >= j) ? A[lane * n + j] : 0;
+		const unsigned long long cand = __ballot(probe != 0);
+		if (cand == 0)
 			continue;
+		const int piv = __ffsll(cand) - 1;
 		bits |= 1ull << j;
 		found++;
-		const u64 inv = dev_invmod(A[piv * n + j], m.p);
 		__syncthreads();
-		if (lane < n) {
-			const u64 s = mulmod<MERS>(A[piv * n + lane], inv, m);
-			A[piv * n + lane] = A[j * n + lane];
-			A[j * n + lane] = s;
-			if (Wm) {
-				const u64 w = mulmod<MERS>(Wm[piv * n + lane], inv, m);
-				Wm[piv * n + lane] = Wm[j * n + lane];
-				Wm[j * n + lane] = w;
+		if (piv != j) {
+			if (lane < n) {
+				u64 x = A[piv * n + lane];
+				A[piv * n + lane] = A[j * n + lane];
+				A[j * n + lane] = x;
+				if (Wm) {
+					x = Wm[piv * n + lane];
+					Wm[piv * n + lane] = Wm[j * n + lane];
+					Wm[j * n + lane] = x;
+				}
 			}
+			if (S && lane == 0)
+				S[piv] = S[j];
 		}
 		__syncthreads();
-		for (int i = 0; i < n; i++) {
-			if (i == j)
-				continue;
-			const u64 mult = A[i * n + j];
+		const u64 pv = A[j * n + j];
+		if (S && lane == 0)
+			S[j] = pv;
+		for (int ib = 0; ib < n; ib += RP) {
+			const int i = ib + li;
+			const bool act = i < n && i != j && k < n;
+			u64 mult = 0, x = 0, y = 0, wx = 0, wy = 0;
+			if (act) {
+				mult = A[i * n + j];
+				x = A[i * n + k];
+				y = A[j * n + k];
+				if (Wm) {
+					wx = Wm[i * n + k];
+					wy = Wm[j * n + k];
+				}
+			}
 			__syncthreads();
-			if (mult != 0 && lane < n) {
+			if (act && mult != 0) {
 				const u64 neg = m.p - mult;
 				Acc acc;
-				acc_set(acc, A[i * n + lane]);
-				acc_mac64(acc, neg, A[j * n + lane]);
-				A[i * n + lane] = acc_reduce<MERS>(acc, m);
+				acc_zero(acc);
+				acc_mac64(acc, pv, x);
+				acc_set(acc, acc_reduce<MERS>(acc, m));
+				acc_mac64(acc, neg, y);
+				A[i * n + k] = acc_reduce<MERS>(acc, m);
 				if (Wm) {
-					acc_set(acc, Wm[i * n + lane]);
-					acc_mac64(acc, neg, Wm[j * n + lane]);
-					Wm[i * n + lane] = acc_reduce<MERS>(acc, m);
+					acc_zero(acc);
+					acc_mac64(acc, pv, wx);
+					acc_set(acc, acc_reduce<MERS>(acc, m));
+					acc_mac64(acc, neg, wy);
+					Wm[i * n + k] = acc_reduce<MERS>(acc, m);
 				}
+				if (S && k == 0)
+					S[i] = mulmod<MERS>(S[i], pv, m);
 			}
 		}
 	}
@@ -332,20 +468,19 @@ __device__ static int gauss_sweep(u64 *A, u64 *Wm, int n, const ModP &m, u64 *ma
 /*
  * semi_inverse(), sequential/lanczos_modp.c:342-438, plus the two n x n coefficient matrices that
  * orthogonalize() derives from it (:460-475), so that the row kernel only streams.
- * small = [vtAv | vtAAv | winv | d | c | vtAvd].
+ * small = [vtAv | vtAAv | winv | d | c | vtAvd].  One wavefront.
  */
 template <int MERS>
 __global__ void __launch_bounds__(64)
-k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, ModP m, int in_loop)
+k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, ModP m, int in_loop)
 {
 	/* in_loop = 0: stand-alone call (blz_semi_inverse): neither obeys nor sets the sticky stop flag */
 	if (in_loop && ctl->stop)
 		return;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	u64 *A = (u64 *)smem_raw;
-	u64 *Wm = A + n * n;
-	const int lane = threadIdx.x;
 	const int nn = n * n;
+	u64 *A = (u64 *)smem_raw, *Wm = A + nn, *S = Wm + nn, *Pre = S + n;
+	const int lane = threadIdx.x;
 	u64 *vtAv = small, *vtAAv = small + nn, *winv = small + 2 * nn, *dvec = small + 3 * nn;
 	u64 *cmat = small + 4 * nn, *vtAvd = small + 5 * nn;
 
@@ -357,31 +492,58 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, ModP m,
 		A[e] = x;
 	}
 	u64 sel = 0, dbits = 0;
-	gauss_sweep<MERS>(A, nullptr, n, m, &sel);			/* phase 1, :349-382 */
+	ff_sweep<MERS>(A, nullptr, nullptr, n, G, m, &sel);		/* phase 1, :349-382: which columns */
 	for (int e = lane; e < nn; e += 64) {				/* :384-388 */
 		const int i = e / n, j = e % n;
 		const bool both = ((sel >> i) & 1) && ((sel >> j) & 1);
 		A[e] = both ? vtAv[e] : 0;
 		Wm[e] = (i == j && ((sel >> i) & 1)) ? 1 : 0;
 	}
-	const int npiv = gauss_sweep<MERS>(A, Wm, n, m, &dbits);	/* phase 2, :389-436 */
-	for (int e = lane; e < nn; e += 64)
-		winv[e] = Wm[e];
+	if (lane < n)
+		S[lane] = 1;
+	const int npiv = ff_sweep<MERS>(A, Wm, S, n, G, m, &dbits);	/* phase 2, :389-436 */
+	/* 1/s_i for all rows from one inversion: Pre[i] = s_0..s_i, then walk back */
+	if (lane == 0) {
+		u64 run = 1;
+		for (int i = 0; i < n; i++) {
+			run = mulmod<MERS>(run, S[i], m);
+			Pre[i] = run;
+		}
+		u64 inv = dev_invmod(run, m.p);
+		for (int i = n - 1; i >= 0; i--) {
+			const u64 si = S[i];
+			S[i] = i ? mulmod<MERS>(inv, Pre[i - 1], m) : inv;
+			inv = mulmod<MERS>(inv, si, m);
+		}
+	}
+	__syncthreads();
+	for (int e = lane; e < nn; e += 64) {
+		const u64 w = mulmod<MERS>(Wm[e], S[e / n], m);
+		Wm[e] = w;
+		winv[e] = w;
+	}
 	if (lane < n)
 		dvec[lane] = (dbits >> lane) & 1;
+	__syncthreads();
 	/* c = -(winv * spliced), vtAvd = -vtAv on the selected columns (:462-475), canonical */
-	if (lane < n) {
-		const bool dj = (dbits >> lane) & 1;
-		for (int i = 0; i < n; i++) {
-			u64 acc = 0;
-			for (int k = 0; k < n; k++) {
-				const u64 sp = dj ? vtAAv[k * n + lane] : vtAv[k * n + lane];
-				acc = addmod(acc, mulmod<MERS>(Wm[i * n + k], sp, m), m.p);
+	for (int e = lane; e < nn; e += 64) {
+		const int i = e / n, j = e % n;
+		const bool dj = (dbits >> j) & 1;
+		const u64 *sp = dj ? vtAAv : vtAv;
+		Acc acc;
+		acc_zero(acc);
+		u32 cnt = 0;
+		for (int k = 0; k < n; k++) {
+			acc_mac64(acc, Wm[i * n + k], sp[k * n + j]);
+			if (++cnt == m.chunk) {
+				cnt = 0;
+				acc_set(acc, acc_reduce<MERS>(acc, m));
 			}
-			cmat[i * n + lane] = acc ? m.p - acc : 0;
-			const u64 x = vtAv[i * n + lane];
-			vtAvd[i * n + lane] = (dj && x) ? m.p - x : 0;
 		}
+		const u64 r = acc_reduce<MERS>(acc, m);
+		cmat[e] = r ? m.p - r : 0;
+		const u64 x = vtAv[e];
+		vtAvd[e] = (dj && x) ? m.p - x : 0;
 	}
 	if (lane == 0) {
 		ctl->npiv = npiv;
@@ -396,13 +558,16 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, ModP m,
 
 hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int in_loop, hipStream_t s)
 {
-	const size_t lds = (size_t)2 * c.n * c.n * sizeof(u64);
+	const size_t lds = ((size_t)2 * c.n * c.n + 2 * c.n) * sizeof(u64);
+	int G = 1;
+	while (G < c.n)
+		G <<= 1;
 #define SEMI(MM)                                                                                                   \
 	do {                                                                                                       \
 		if (lds > 48 * 1024)                                                                               \
 			hipFuncSetAttribute((const void *)k_semi_inverse<MM>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
 					    (int)lds);                                                             \
-		hipLaunchKernelGGL((k_semi_inverse<MM>), dim3(1), dim3(64), lds, s, small, ctl, c.n, c.m, in_loop); \
+		hipLaunchKernelGGL((k_semi_inverse<MM>), dim3(1), dim3(64), lds, s, small, ctl, c.n, G, c.m, in_loop); \
 	} while (0)
 	if (c.mers == 61)
 		SEMI(61);
@@ -485,26 +650,89 @@ k_orthogonalize(W *__restrict__ V, const W *__restrict__ AV, W *__restrict__ P, 
 	}
 }
 
+/*
+ * Fast path for n = NT in {1,2,4,8,16} (needs m.chunk >= 2*NT so that a row's sums fit one reduction):
+ * lane j of a group keeps column j of c, vtAvd and winv in registers (3*NT words), loads v[r,j], Av[r,j],
+ * p[r,j] with three coalesced loads, and receives v[r,k], p[r,k] by broadcast inside the group.
+ * No LDS, no barrier: pure streaming with 3*NT 64x64-bit MACs per output pair.
+ */
+template <typename W, int MERS, int NT>
+__global__ void __launch_bounds__(BLOCK)
+k_orthogonalize_fast(W *__restrict__ V, const W *__restrict__ AV, W *__restrict__ P, long long rows, ModP m,
+		     const u64 *__restrict__ small, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int GPB = BLOCK / NT, NN = NT * NT;
+	const int t = threadIdx.x, lane = t & 63, j = t & (NT - 1), gbase = lane - j;
+	u64 cc[NT], vd[NT], ww[NT];
+#pragma unroll
+	for (int k = 0; k < NT; k++) {
+		ww[k] = small[2 * NN + k * NT + j];
+		cc[k] = small[4 * NN + k * NT + j];
+		vd[k] = small[5 * NN + k * NT + j];
+	}
+	const bool dj = small[3 * NN + j] != 0;
+	const long long g0 = (long long)blockIdx.x * GPB + t / NT, ng = (long long)gridDim.x * GPB;
+	for (long long r = g0; r < rows; r += ng) {
+		const size_t at = (size_t)r * NT + j;
+		const u64 vv = V[at], aa = AV[at], pp = P[at];
+		Acc av, ap;
+		acc_set(av, dj ? aa : vv);
+		acc_set(ap, dj ? 0 : pp);
+#pragma unroll
+		for (int k = 0; k < NT; k++) {
+			const u64 vk = NT == 1 ? vv : shfl64(vv, gbase + k), pk = NT == 1 ? pp : shfl64(pp, gbase + k);
+			acc_mac64(av, vk, cc[k]);
+			acc_mac64(av, pk, vd[k]);
+			acc_mac64(ap, vk, ww[k]);
+		}
+		V[at] = (W)acc_reduce<MERS>(av, m);
+		P[at] = (W)acc_reduce<MERS>(ap, m);
+	}
+}
+
 template <typename W, int MERS>
 static hipError_t ortho_dispatch(const KernelCfg &c, W *V, const W *AV, W *P, int64_t rows, const u64 *small,
 				 const DevCtl *ctl, hipStream_t s)
 {
 	if (rows == 0)
 		return hipSuccess;
+	const int n = c.n;
+	const long long cap = (long long)c.num_cu * 8;
+	if ((n == 1 || n == 2 || n == 4 || n == 8 || n == 16) && c.m.chunk >= 2u * (unsigned)n) {
+		const long long gpb = BLOCK / n;
+		long long blocks = (rows + gpb - 1) / gpb;
+		if (blocks > cap)
+			blocks = cap;
+#define ORTHO_FAST(NN)                                                                                               \
+	case NN:                                                                                                     \
+		hipLaunchKernelGGL((k_orthogonalize_fast<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, P, \
+				   (long long)rows, c.m, small, ctl);                                                 \
+		break;
+		switch (n) {
+			ORTHO_FAST(1)
+			ORTHO_FAST(2)
+			ORTHO_FAST(4)
+			ORTHO_FAST(8)
+			ORTHO_FAST(16)
+		}
+#undef ORTHO_FAST
+		return hipGetLastError();
+	}
 	int G = 1;
-	while (G < c.n)
+	while (G < n)
 		G <<= 1;
 	const int gpb = BLOCK / G;
-	const size_t lds = ((size_t)3 * c.n * c.n + (size_t)2 * gpb * c.n) * sizeof(u64);
+	const size_t lds = ((size_t)3 * n * n + (size_t)2 * gpb * n) * sizeof(u64);
 	if (lds > 48 * 1024)
 		hipFuncSetAttribute((const void *)k_orthogonalize<W, MERS>, hipFuncAttributeMaxDynamicSharedMemorySize,
 				    (int)lds);
 	long long blocks = (rows + gpb - 1) / gpb;
-	const long long cap = (long long)c.num_cu * 8;
 	if (blocks > cap)
 		blocks = cap;
 	hipLaunchKernelGGL((k_orthogonalize<W, MERS>), dim3((unsigned)blocks), dim3(BLOCK), lds, s, V, AV, P,
-			   (long long)rows, c.n, G, c.m, small, ctl);
+			   (long long)rows, n, G, c.m, small, ctl);
 	return hipGetLastError();
 }
 
