@@ -108,6 +108,8 @@ struct blz_ctx {
 	DevCtl *ctl = nullptr;
 	DevCtl host_ctl{};
 	ncclComm_t comm = nullptr;
+	bool external_exchange = false;
+	bool force_comm = false;	/* BLZ_FORCE_COMM=1: issue the collectives even on one rank (plumbing test) */
 };
 
 /* HIP-event span around one enqueue on the context's stream (only while profiling is on). */
@@ -268,41 +270,20 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 	c->row_side[0] = right ? 1 : 0;		/* rows of M   */
 	c->row_side[1] = right ? 0 : 1;		/* rows of M^T */
 
-	blz_csr full[2];
-	int rc;
-	if ((rc = blz_csr_from_coo(M, 0, 1, &full[0])) != BLZ_OK)
+	blz_csr slabs[2];
+	c->bounds[0].assign((size_t)nranks + 1, 0);
+	c->bounds[1].assign((size_t)nranks + 1, 0);
+	int rc = blz_shard_matrix(M, right, rank, nranks, slabs, c->bounds[0].data(), c->bounds[1].data(), c->stride);
+	if (rc != BLZ_OK)
 		return rc;
-	if ((rc = blz_csr_from_coo(M, 1, 1, &full[1])) != BLZ_OK) {
-		blz_csr_free(&full[0]);
-		return rc;
-	}
-	for (int t = 0; t < 2; t++) {
-		const int sd = c->row_side[t];
-		c->bounds[sd].assign((size_t)nranks + 1, 0);
-		blz_partition_rows(&full[t], nranks, c->bounds[sd].data());
-		int64_t mx = 0;
-		for (int g = 0; g < nranks; g++)
-			mx = std::max<int64_t>(mx, c->bounds[sd][g + 1] - c->bounds[sd][g]);
-		c->stride[sd] = mx;
+	for (int sd = 0; sd < 2; sd++) {
 		c->first[sd] = c->bounds[sd][rank];
 		c->count[sd] = c->bounds[sd][rank + 1] - c->bounds[sd][rank];
 	}
-	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
-		const int rs = c->row_side[t], cs = 1 - rs;
-		blz_csr slab;
-		if (nranks == 1) {
-			rc = upload_csr(c, full[t], c->csr[t]);
-		} else {
-			rc = blz_csr_slab(&full[t], c->bounds[rs][rank], c->bounds[rs][rank + 1], &slab);
-			if (rc == BLZ_OK) {
-				blz_remap_columns(&slab, c->bounds[cs].data(), nranks, c->stride[cs]);
-				rc = upload_csr(c, slab, c->csr[t]);
-				blz_csr_free(&slab);
-			}
-		}
-	}
-	blz_csr_free(&full[0]);
-	blz_csr_free(&full[1]);
+	for (int t = 0; t < 2 && rc == BLZ_OK; t++)
+		rc = upload_csr(c, slabs[t], c->csr[t]);
+	blz_csr_free(&slabs[0]);
+	blz_csr_free(&slabs[1]);
 	if (rc != BLZ_OK)
 		return rc;
 
@@ -465,7 +446,7 @@ extern "C" int blz_init_v(blz_ctx *c)
 
 static int allgather_block(blz_ctx *c, int block)
 {
-	if (c->nranks == 1)
+	if (c->external_exchange || (c->nranks == 1 && !(c->force_comm && c->comm)))
 		return BLZ_OK;
 	Span sp(c, block == BLZ_V ? PK_AG_V : PK_AG_T);
 	if (!c->comm)
@@ -478,7 +459,7 @@ static int allgather_block(blz_ctx *c, int block)
 
 static int allreduce_dots(blz_ctx *c)
 {
-	if (c->nranks == 1)
+	if (c->external_exchange || (c->nranks == 1 && !(c->force_comm && c->comm)))
 		return BLZ_OK;
 	if (!c->comm)
 		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
@@ -604,6 +585,8 @@ extern "C" int blz_iterate(blz_ctx *c, int max_iters, int *done, int *stopped, f
 	NEED_MATRIX(c);
 	if (max_iters < 0)
 		return blz_fail(BLZ_EINVAL, "blz_iterate: max_iters < 0");
+	if (c->external_exchange && c->nranks > 1)
+		return blz_fail(BLZ_EINVAL, "blz_iterate: the context is in external-exchange mode");
 	const long long before = c->host_ctl.iterations;
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	for (int it = 0; it < max_iters; it++) {
@@ -644,7 +627,7 @@ extern "C" int blz_final_check(blz_ctx *c, int *v_nonzero, int *vtm_zero)
 	HIPCHK(hipMemset(&c->ctl->flag_v_nonzero, 0, 2 * sizeof(int)));
 	HIPCHK(launch_any_nonzero(c->cfg, slab_ptr(c, BLZ_V), c->count[0] * c->cfg.n, &c->ctl->flag_v_nonzero, c->stream));
 	HIPCHK(launch_any_nonzero(c->cfg, slab_ptr(c, BLZ_TMP), c->count[1] * c->cfg.n, &c->ctl->flag_t_nonzero, c->stream));
-	if (c->nranks > 1) {
+	if (c->nranks > 1 && !c->external_exchange) {
 		if (!c->comm)
 			return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
 		NCCLCHK(g_rccl.AllReduce(&c->ctl->flag_v_nonzero, &c->ctl->flag_v_nonzero, 2, ncclInt32, ncclSum, c->comm,
@@ -728,6 +711,14 @@ extern "C" int blz_sync(blz_ctx *c)
 	return BLZ_OK;
 }
 
+extern "C" int blz_set_exchange_mode(blz_ctx *c, int external)
+{
+	if (!c)
+		return blz_fail(BLZ_EINVAL, "blz_set_exchange_mode: NULL context");
+	c->external_exchange = external != 0;
+	return BLZ_OK;
+}
+
 extern "C" int blz_comm_unique_id(void *id_out, size_t id_bytes)
 {
 	if (!id_out || id_bytes < sizeof(ncclUniqueId))
@@ -752,5 +743,7 @@ extern "C" int blz_comm_init(blz_ctx *c, const void *id, size_t id_bytes, int ra
 	ncclUniqueId uid;
 	memcpy(&uid, id, sizeof uid);
 	NCCLCHK(g_rccl.CommInitRank(&c->comm, nranks, uid, rank));
+	const char *f = getenv("BLZ_FORCE_COMM");
+	c->force_comm = f && f[0] == '1';
 	return BLZ_OK;
 }

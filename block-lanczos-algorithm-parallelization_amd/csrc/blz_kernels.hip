@@ -9,6 +9,8 @@
  */
 #include "blz_kernels.h"
 
+#include <type_traits>
+
 #define BLOCK 256
 
 /* ----------------------------------------------------------------------------- SpMV */
@@ -223,7 +225,9 @@ k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long ro
 	__shared__ u64 red[WAVES][SLOTS][NT];
 	const int t = threadIdx.x, lane = t & 63, i = t & (NT - 1), gbase = lane - i;
 	const long long g0 = (long long)blockIdx.x * GPB + t / NT, ng = (long long)gridDim.x * GPB;
-	Acc a1[NT], a2[H];
+	/* the 8-register lazy accumulator while the register file allows (13 of them at NT = 8) */
+	using DotAcc = typename std::conditional<(NT <= 8 && sizeof(W) == 8), AccL, Acc>::type;
+	DotAcc a1[NT], a2[H];
 #pragma unroll
 	for (int q = 0; q < NT; q++)
 		acc_zero(a1[q]);
@@ -677,7 +681,7 @@ k_orthogonalize_fast(W *__restrict__ V, const W *__restrict__ AV, W *__restrict_
 	for (long long r = g0; r < rows; r += ng) {
 		const size_t at = (size_t)r * NT + j;
 		const u64 vv = V[at], aa = AV[at], pp = P[at];
-		Acc av, ap;
+		typename std::conditional<sizeof(W) == 8, AccL, Acc>::type av, ap;
 		acc_set(av, dj ? aa : vv);
 		acc_set(ap, dj ? 0 : pp);
 #pragma unroll

@@ -364,6 +364,54 @@ void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t str
 	}
 }
 
+int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, blz_csr slabs[2], int64_t *bounds0,
+		     int64_t *bounds1, int64_t stride[2])
+{
+	if (!M || !slabs || !bounds0 || !bounds1 || !stride || nranks < 1 || rank < 0 || rank >= nranks)
+		return blz_fail(BLZ_EINVAL, "blz_shard_matrix: bad argument");
+	memset(slabs, 0, 2 * sizeof slabs[0]);
+	blz_csr full[2];
+	int rc;
+	if ((rc = blz_csr_from_coo(M, 0, 1, &full[0])) != BLZ_OK)
+		return rc;
+	if ((rc = blz_csr_from_coo(M, 1, 1, &full[1])) != BLZ_OK) {
+		blz_csr_free(&full[0]);
+		return rc;
+	}
+	/* rows of M live on side 0 for a left kernel and on side 1 for a right kernel; M^T the other way */
+	int64_t *bounds[2] = { bounds0, bounds1 };
+	const int row_side[2] = { right ? 1 : 0, right ? 0 : 1 };
+	for (int t = 0; t < 2; t++) {
+		const int sd = row_side[t];
+		blz_partition_rows(&full[t], nranks, bounds[sd]);
+		int64_t mx = 0;
+		for (int g = 0; g < nranks; g++)
+			if (bounds[sd][g + 1] - bounds[sd][g] > mx)
+				mx = bounds[sd][g + 1] - bounds[sd][g];
+		stride[sd] = mx;
+	}
+	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
+		const int rs = row_side[t], cs = 1 - rs;
+		if (nranks == 1) {
+			slabs[t] = full[t];		/* hand the arrays over */
+			memset(&full[t], 0, sizeof full[t]);
+		} else {
+			rc = blz_csr_slab(&full[t], bounds[rs][rank], bounds[rs][rank + 1], &slabs[t]);
+			if (rc == BLZ_OK) {
+				blz_remap_columns(&slabs[t], bounds[cs], nranks, stride[cs]);
+				slabs[t].cols = stride[cs] * nranks;
+			}
+		}
+	}
+	blz_csr_free(&full[0]);
+	blz_csr_free(&full[1]);
+	if (rc != BLZ_OK) {
+		blz_csr_free(&slabs[0]);
+		blz_csr_free(&slabs[1]);
+	}
+	return rc;
+}
+
 /* --------------------------------------------------------------------------------- RNG */
 
 /* sequential/lanczos_modp.c:67 */

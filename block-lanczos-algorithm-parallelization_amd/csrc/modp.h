@@ -140,6 +140,49 @@ MODP_DEV u64 mulmod(u64 x, u64 y, const ModP &m)
 	return reduce128<MERS>((u64)(t >> 64), (u64)t, m);
 }
 
+/*
+ * Lazy 128-bit accumulator for sums of 64x64-bit products (the dense n x n work): the four 32x32 partial
+ * products go to three independent 64-bit columns, each with one v_mad_u64_u32 and no cross-column carry
+ * chain; wrap-arounds of the two low columns are counted instead of propagated.
+ *     value = L + M*2^32 + (H + lc)*2^64 + mc*2^96
+ * 7 VALU instructions per MAC (4 mad + 3 addc) against ~13 for the compiler's 128-bit sequence, which has to
+ * shuffle odd register pairs (gfx950 wants 64-bit operands in even-aligned pairs).  Callers keep the true sum
+ * below 2^128 (and H below 2^64: at most 2^64 / (p>>32)^2 products) between reductions -- the same chunk rule
+ * as for Acc.  The carry-out of v_mad_u64_u32 is consumed by the next instruction through VCC, exactly like
+ * the add_co/addc_co pairs hipcc emits for every 64-bit add.
+ */
+struct AccL {
+	u64 L, M, H;
+	u32 lc, mc;
+};
+
+MODP_DEV void acc_zero(AccL &a) { a.L = 0; a.M = 0; a.H = 0; a.lc = 0; a.mc = 0; }
+MODP_DEV void acc_set(AccL &a, u64 x) { a.L = x; a.M = 0; a.H = 0; a.lc = 0; a.mc = 0; }
+
+MODP_DEV void acc_mac64(AccL &a, u64 x, u64 y)
+{
+	const u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+	asm("v_mad_u64_u32 %0, vcc, %5, %7, %0\n\t"
+	    "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+	    "v_mad_u64_u32 %1, vcc, %5, %8, %1\n\t"
+	    "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+	    "v_mad_u64_u32 %1, vcc, %6, %7, %1\n\t"
+	    "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+	    "v_mad_u64_u32 %2, vcc, %6, %8, %2"
+	    : "+v"(a.L), "+v"(a.M), "+v"(a.H), "+v"(a.lc), "+v"(a.mc)
+	    : "v"(x0), "v"(x1), "v"(y0), "v"(y1)
+	    : "vcc");
+}
+
+template <int MERS>
+MODP_DEV u64 acc_reduce(const AccL &a, const ModP &m)
+{
+	const u64 t = a.M << 32;
+	const u64 lo = a.L + t;
+	const u64 hi = a.H + a.lc + (a.M >> 32) + ((u64)a.mc << 32) + (lo < t);
+	return reduce128<MERS>(hi, lo, m);
+}
+
 MODP_DEV u64 addmod(u64 x, u64 y, u64 p)
 {
 	const u64 s = x + y;		/* x, y < p < 2^62 */

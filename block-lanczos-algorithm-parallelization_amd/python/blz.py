@@ -127,6 +127,23 @@ def _partition(A, parts):
     return list(b)
 
 
+def shard_matrix(M, right, rank, nranks):
+    """blz_shard_matrix(): the slabs, bounds and strides rank `rank` of `nranks` works with (host only)."""
+    slabs = (Csr * 2)()
+    b0 = (C.c_int64 * (nranks + 1))()
+    b1 = (C.c_int64 * (nranks + 1))()
+    stride = (C.c_int64 * 2)()
+    check(lib().blz_shard_matrix(C.byref(M.c), C.c_int(int(right)), C.c_int(rank), C.c_int(nranks), slabs, b0, b1, stride))
+    out = []
+    for A in slabs:
+        rp = np.ctypeslib.as_array(A.row_ptr, (A.rows + 1,)).copy()
+        ci = np.ctypeslib.as_array(A.col_idx, (max(A.nnz, 1),))[:A.nnz].copy()
+        va = np.ctypeslib.as_array(A.val, (max(A.nnz, 1),))[:A.nnz].copy() if A.val else np.ones(A.nnz, np.uint32)
+        out.append(dict(rows=int(A.rows), cols=int(A.cols), nnz=int(A.nnz), row_ptr=rp, col_idx=ci, val=va))
+        lib().blz_csr_free(C.byref(A))
+    return dict(slabs=out, bounds=[list(b0), list(b1)], stride=list(stride))
+
+
 def rng_draws(count):
     s = (C.c_uint64 * 4)()
     lib().blz_rng_seed(s)
@@ -271,6 +288,9 @@ class Context:
         cnt = (C.c_int64 * 8)()
         check(lib().blz_profile_read(self.h, ms, cnt))
         return {k: dict(ms_total=float(ms[i]), launches=int(cnt[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
+
+    def set_exchange_mode(self, external):
+        check(lib().blz_set_exchange_mode(self.h, C.c_int(int(external))))
 
     def sync(self):
         check(lib().blz_sync(self.h))

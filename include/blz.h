@@ -90,6 +90,18 @@ void blz_csr_free(blz_csr *A);
 /* nnz-balanced contiguous row partition: bounds[0]=0 <= ... <= bounds[parts]=rows. */
 int blz_partition_rows(const blz_csr *A, int parts, int64_t *bounds);
 
+/* What rank `rank` of `nranks` keeps of M for the solve (right=0: x*M=0, right=1: M*x=0).
+ * "Side 0" is the row space of v/Av/p, "side 1" that of tmp (sequential/lanczos_modp.c:592-593).
+ *   bounds0/bounds1 [nranks+1]  nnz-balanced row partition of each side
+ *   stride[2]                   largest slab of each side: blocks are kept in the rank-major padded
+ *                               layout  position(row r of rank g) = g*stride + (r - bounds[g])
+ *                               so that an in-place all-gather of equal-sized slabs rebuilds a block
+ *   slabs[0] = this rank's rows of M, slabs[1] = its rows of M^T, column indices already rewritten
+ *              to positions in the padded layout of the opposite side (identity when nranks == 1).
+ * This is the whole multi-GPU data layout; blz_set_matrix uploads exactly these slabs. */
+int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, blz_csr slabs[2],
+		     int64_t *bounds0, int64_t *bounds1, int64_t stride[2]);
+
 /* rng_state/random64(), sequential/lanczos_modp.c:67-87, and the initialisation
  * `v[i] = random64() % prime` in row-major order (:624-625). */
 void blz_rng_seed(uint64_t state[4]);
@@ -185,6 +197,12 @@ int blz_sync(blz_ctx *ctx);
 #define BLZ_PROFILE_CLASSES 8
 int blz_profile(blz_ctx *ctx, int enable);
 int blz_profile_read(blz_ctx *ctx, double ms_sum[BLZ_PROFILE_CLASSES], int64_t launches[BLZ_PROFILE_CLASSES]);
+
+/* Exchange mode of a multi-rank context: 0 (default) = the library issues the RCCL collectives itself
+ * inside blz_iterate / blz_block_dot; 1 = external: collectives are skipped and the caller moves the
+ * slabs between ranks with blz_get_block / blz_set_block / blz_get_small / blz_set_small (used by the
+ * single-GPU emulation tests of the sharded schedule; blz_iterate is refused in this mode). */
+int blz_set_exchange_mode(blz_ctx *ctx, int external);
 
 /* Multi-GPU (one process per GPU).  id_bytes = ncclUniqueId from blz_comm_unique_id() on rank 0,
  * broadcast by the caller (bench.py uses torch.distributed for that and nothing else). */

@@ -1,0 +1,60 @@
+"""The multi-GPU schedule of libblz_hip.so (enqueue_iteration in csrc/blz_api.hip), restated for the test-suite
+with a pluggable exchange and the CPU oracle as the compute backend.
+
+It consumes EXACTLY the data layout the product uses -- blz_shard_matrix(): nnz-balanced row slabs of M and M^T,
+column indices rewritten to the rank-major padded layout, equal-sized slabs for an in-place all-gather -- and runs
+the same sequence of steps:
+
+    all-gather(v) -> tmp_g = B[C_g,:] v -> all-gather(tmp) -> Av_g = B^T[R_g,:] tmp
+    -> local v^T Av, Av^T Av -> all-reduce(sum, u64) then mod p -> semi_inverse (replicated) -> local orthogonalize
+
+`exchange` provides allgather(padded_slab) -> concatenated array and allreduce_sum(int array) -> array.
+Used by tests/test_sharded_gloo.py (torch.distributed gloo, world_size 2, CPU only).  Test infrastructure only.
+"""
+import numpy as np
+
+import blz
+import oracle as orc
+
+
+def slab_as_coo(slab):
+    rows = slab["rows"]
+    ri = np.repeat(np.arange(rows, dtype=np.int32), np.diff(slab["row_ptr"].astype(np.int64)))
+    return orc.Matrix(rows, slab["cols"], ri, slab["col_idx"], slab["val"])
+
+
+def run_rank(M, prime, n, right, rank, world, exchange, max_iters=10 ** 9):
+    sh = blz.shard_matrix(M, right, rank, world)
+    b0, b1 = sh["bounds"]
+    s0, s1 = sh["stride"]
+    first0, cnt0 = b0[rank], b0[rank + 1] - b0[rank]
+    cnt1 = b1[rank + 1] - b1[rank]
+    # SpMV 1 uses M^T for a left kernel and M for a right kernel (sequential/lanczos_modp.c:635); SpMV 2 the other
+    A1 = slab_as_coo(sh["slabs"][0 if right else 1])
+    A2 = slab_as_coo(sh["slabs"][1 if right else 0])
+    assert A1.nrows == cnt1 and A2.nrows == cnt0
+    nrows_v = M.ncols if right else M.nrows
+    v = blz.rng_fill(nrows_v * n, prime)[first0 * n:(first0 + cnt0) * n].copy()
+    pb = np.zeros(cnt0 * n, dtype=np.uint64)
+
+    def padded(x, stride):
+        out = np.zeros(stride * n, dtype=np.uint64)
+        out[:x.size] = x
+        return out
+
+    its = 0
+    tmp = np.zeros(cnt1 * n, dtype=np.uint64)
+    while its < max_iters:
+        vg = exchange.allgather(padded(v, s0))
+        tmp = orc.spmv(A1, vg, False, n, prime)
+        tg = exchange.allgather(padded(tmp, s1))
+        Av = orc.spmv(A2, tg, False, n, prime)
+        a, b = orc.block_dot(cnt0, Av, v, n, prime)
+        tot = exchange.allreduce_sum(np.concatenate([a, b]))
+        vtAv, vtAAv = tot[:n * n] % prime, tot[n * n:] % prime
+        npiv, winv, d = orc.semi_inverse(vtAv, n, prime)
+        if npiv == 0:
+            break
+        v, pb = orc.orthogonalize(v, pb, d, vtAv, vtAAv, winv, cnt0, Av, n, prime)
+        its += 1
+    return dict(v=v, p=pb, tmp=tmp, first=first0, count=cnt0, iterations=its, bounds=sh["bounds"], stride=sh["stride"])
