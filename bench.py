@@ -159,6 +159,19 @@ def main():
     kernels["block_dot"]["alg_bytes"] = 2 * loc_v * n * word
     kernels["orthogonalize"]["alg_bytes"] = 5 * loc_v * n * word
 
+    # HBM-side traffic of the SpMV kernel from the committed rocprofv3 PMC passes of this same command
+    # (tools/gpu_profile.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs; bench.py cannot collect PMCs itself).
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}_n{world}.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        for name, rec in tj.items():
+            if name.startswith("k_spmv") and "FETCH_SIZE_bytes_per_launch" in rec and "WRITE_SIZE_bytes_per_launch" in rec:
+                # 64-byte row gathers are counted at face value by FETCH_SIZE (it equals nnz*64 B + the matrix stream
+                # here); the guide's x2 correction concerns 128-byte streaming requests only.
+                traffic = rec["FETCH_SIZE_bytes_per_launch"] + rec["WRITE_SIZE_bytes_per_launch"]
+                traffic_src = os.path.relpath(tpath, ROOT)
+
     macs_per_step = 2 * M.nnz * n
     value = macs_per_step * args.steps / elapsed
 
@@ -189,7 +202,8 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "alg_bytes_per_launch": alg_bytes,
             "ms_per_launch": t_spmv_ms,
         },

@@ -108,6 +108,7 @@ struct blz_ctx {
 	DevCtl *ctl = nullptr;
 	DevCtl host_ctl{};
 	ncclComm_t comm = nullptr;
+	bool fuse_dot = true;		/* BLZ_NO_FUSE=1 keeps block_dot as its own kernel (A/B measurements) */
 	bool external_exchange = false;
 	bool force_comm = false;	/* BLZ_FORCE_COMM=1: issue the collectives even on one rank (plumbing test) */
 };
@@ -190,12 +191,18 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	c->cfg.mers = modp_mersenne(prime);
 	c->cfg.m = make_modp(prime);
 	c->cfg.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	c->cfg.spmv_blocks_per_cu = 0;	/* 0 = choose from the row length */
+	if (const char *bp = getenv("BLZ_SPMV_BLOCKS_PER_CU"))
+		if (atoi(bp) >= 1 && atoi(bp) <= 64)
+			c->cfg.spmv_blocks_per_cu = atoi(bp);
+	const char *nf = getenv("BLZ_NO_FUSE");
+	c->fuse_dot = !(nf && nf[0] == '1');
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate(&c->ev0));
 	HIPCHK(hipEventCreate(&c->ev1));
 	HIPCHK(hipMalloc(&c->small, small_words(n) * sizeof(u64)));
 	HIPCHK(hipMemset(c->small, 0, small_words(n) * sizeof(u64)));
-	c->max_dot_blocks = c->cfg.num_cu * 4;
+	c->max_dot_blocks = c->cfg.num_cu * 8;
 	HIPCHK(hipMalloc(&c->partial, (size_t)c->max_dot_blocks * 2 * n * n * sizeof(u64)));
 	HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
@@ -571,8 +578,22 @@ static int enqueue_iteration(blz_ctx *c)
 	if ((rc = allgather_block(c, BLZ_V)) != BLZ_OK) return rc;
 	if ((rc = enqueue_spmv(c, !c->right, BLZ_V, BLZ_TMP)) != BLZ_OK) return rc;	/* :635 */
 	if ((rc = allgather_block(c, BLZ_TMP)) != BLZ_OK) return rc;
-	if ((rc = enqueue_spmv(c, c->right, BLZ_TMP, BLZ_AV)) != BLZ_OK) return rc;	/* :636 */
-	if ((rc = enqueue_dot(c)) != BLZ_OK) return rc;					/* :640 */
+	if (c->fuse_dot && spmv_dot_supported(c->cfg) && c->csr[c->right].rows > 0) {
+		int nb = 0;							/* :636 + :640 in one kernel */
+		{
+			Span sp(c, PK_SPMV2);
+			HIPCHK(launch_spmv_dot(c->cfg, c->csr[c->right], c->blk[BLZ_TMP], slab_ptr(c, BLZ_AV), slab_ptr(c, BLZ_V),
+					       c->partial, c->max_dot_blocks, &nb, c->ctl, c->stream));
+		}
+		{
+			Span sp(c, PK_DOT);
+			HIPCHK(launch_dot_finalize(c->cfg, c->partial, nb, c->small, c->ctl, c->stream));
+		}
+		if ((rc = allreduce_dots(c)) != BLZ_OK) return rc;
+	} else {
+		if ((rc = enqueue_spmv(c, c->right, BLZ_TMP, BLZ_AV)) != BLZ_OK) return rc;	/* :636 */
+		if ((rc = enqueue_dot(c)) != BLZ_OK) return rc;				/* :640 */
+	}
 	{
 		Span sp(c, PK_SEMI);
 		HIPCHK(launch_semi_inverse(c->cfg, c->small, c->ctl, 1, c->stream));	/* :644 */

@@ -13,6 +13,19 @@
 
 #define BLOCK 256
 
+/* 64-bit cross-lane read (absolute lane of the wave) */
+MODP_DEV u64 shfl64(u64 x, int src)
+{
+	const u32 lo = (u32)__shfl((int)(u32)x, src, 64), hi = (u32)__shfl((int)(u32)(x >> 32), src, 64);
+	return ((u64)hi << 32) | lo;
+}
+
+MODP_DEV u64 shfl_xor64(u64 x, int mask)
+{
+	const u32 lo = (u32)__shfl_xor((int)(u32)x, mask, 64), hi = (u32)__shfl_xor((int)(u32)(x >> 32), mask, 64);
+	return ((u64)hi << 32) | lo;
+}
+
 /* ----------------------------------------------------------------------------- SpMV */
 
 /*
@@ -24,18 +37,27 @@
 template <typename W, int G, int MERS>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
-       const W *__restrict__ X, W *__restrict__ Y, long long rows, int n, ModP m,
+       const W *__restrict__ X, W *__restrict__ Y, long long rows, int n, int split_log2, ModP m,
        const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
 	const int lane = threadIdx.x & (G - 1);
 	const int xl = lane < n ? lane : 0;
-	const long long g0 = ((long long)blockIdx.x * BLOCK + threadIdx.x) / G;
-	const long long ng = (long long)gridDim.x * (BLOCK / G);
+	/* 2^split_log2 adjacent groups of one wavefront share a row (few, long rows: keeps every CU busy and
+	 * shortens the dependent chain); their 128-bit partial sums are added across lanes before the reduction */
+	const long long gid = ((long long)blockIdx.x * BLOCK + threadIdx.x) / G;
+	const long long g0 = gid >> split_log2;
+	const u32 part = (u32)gid & ((1u << split_log2) - 1u);
+	const long long ng = ((long long)gridDim.x * (BLOCK / G)) >> split_log2;
 	for (long long r = g0; r < rows; r += ng) {
-		u32 k = rp[r];
-		const u32 e = rp[r + 1];
+		u32 k = rp[r], e = rp[r + 1];
+		if (split_log2) {
+			const u32 len = e - k, per = (len + (1u << split_log2) - 1u) >> split_log2;
+			const u32 lo = k + part * per;
+			k = lo < e ? lo : e;
+			e = (lo + per) < e ? (lo + per) : e;
+		}
 		Acc acc;
 		acc_zero(acc);
 		if (va) {
@@ -64,7 +86,13 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 			for (; k < e; k++)
 				acc_add(acc, X[(size_t)ci[k] * n + xl]);
 		}
-		if (lane < n)
+		for (int off = G; off < (G << split_log2); off <<= 1) {
+			const u64 olo = shfl_xor64(acc.lo, off), ohi = shfl_xor64(acc.hi, off);
+			const u64 t = acc.lo + olo;
+			acc.hi += ohi + (t < olo);
+			acc.lo = t;
+		}
+		if (lane < n && part == 0)
 			Y[(size_t)r * n + lane] = (W)acc_reduce<MERS>(acc, m);
 	}
 }
@@ -79,14 +107,22 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 	while (G < c.n)
 		G <<= 1;
 	const long long groups_per_block = BLOCK / G;
-	long long blocks = (A.rows + groups_per_block - 1) / groups_per_block;
-	const long long cap = (long long)c.num_cu * 8;
+	/* measured on MI355X (tools/tune_spmv.py): rows of >= ~12 entries run best with 4 resident blocks per CU,
+	 * short rows want 8; few long rows are split over up to 64/G groups */
+	const double avg = (double)A.nnz / (double)A.rows;
+	int split_log2 = 0;
+	while ((G << (split_log2 + 1)) <= 64 && (double)A.rows * (1 << split_log2) < 2.0 * c.num_cu * 8 * groups_per_block
+	       && avg / (1 << (split_log2 + 1)) >= 4.0)
+		split_log2++;
+	int per_cu = c.spmv_blocks_per_cu > 0 ? c.spmv_blocks_per_cu : (avg / (1 << split_log2) >= 12.0 ? 4 : 8);
+	long long blocks = ((A.rows << split_log2) + groups_per_block - 1) / groups_per_block;
+	const long long cap = (long long)c.num_cu * per_cu;
 	if (blocks > cap)
 		blocks = cap;
 #define SPMV_CASE(GG)                                                                                             \
 	case GG:                                                                                                  \
 		hipLaunchKernelGGL((k_spmv<W, GG, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr,  \
-				   A.col_idx, A.val, X, Y, (long long)A.rows, c.n, c.m, ctl);                    \
+				   A.col_idx, A.val, X, Y, (long long)A.rows, c.n, split_log2, c.m, ctl);       \
 		break;
 	switch (G) {
 		SPMV_CASE(1)
@@ -193,50 +229,35 @@ k_block_dot(const W *__restrict__ V, const W *__restrict__ AV, long long rows, l
 	}
 }
 
-/* 64-bit cross-lane read (absolute lane of the wave) */
-MODP_DEV u64 shfl64(u64 x, int src)
-{
-	const u32 lo = (u32)__shfl((int)(u32)x, src, 64), hi = (u32)__shfl((int)(u32)(x >> 32), src, 64);
-	return ((u64)hi << 32) | lo;
-}
-
-MODP_DEV u64 shfl_xor64(u64 x, int mask)
-{
-	const u32 lo = (u32)__shfl_xor((int)(u32)x, mask, 64), hi = (u32)__shfl_xor((int)(u32)(x >> 32), mask, 64);
-	return ((u64)hi << 32) | lo;
-}
-
 /*
- * Fast path for n = NT in {1,2,4,8,16}: a group of NT lanes owns one block row, lane i holds
- * v[r,i] and Av[r,i] (two fully coalesced loads per row), and the operands Av[r,(i+t) mod NT] arrive
- * by rotation inside the group.  Lane i accumulates
+ * Block inner products for n = NT in {1,2,4,8,16}: a group of NT lanes owns one block row, lane i holds
+ * v[r,i] and Av[r,i], and the operands Av[r,(i+t) mod NT] arrive by rotation inside the group.  Lane i
+ * accumulates
  *     vtAv [i][(i+t)%NT]  for t = 0..NT-1
  *     vtAAv[i][(i+t)%NT]  for t = 0..NT/2   (Av^T Av is symmetric for ANY input, so half is enough)
- * in 128-bit registers, reduced every m.chunk rows.
+ * in 128-bit registers, reduced every m.chunk rows.  Used stand-alone (k_block_dot_fast) and as the epilogue
+ * of the second SpMV (k_spmv_dot), where its VALU work hides under the gather latency.
  */
-template <typename W, int MERS, int NT>
-__global__ void __launch_bounds__(BLOCK)
-k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long rows, ModP m,
-		 u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
-{
-	if (ctl->stop)
-		return;
-	constexpr int GPB = BLOCK / NT, H = NT / 2 + 1, SLOTS = NT + H, WAVES = BLOCK / 64;
-	__shared__ u64 red[WAVES][SLOTS][NT];
-	const int t = threadIdx.x, lane = t & 63, i = t & (NT - 1), gbase = lane - i;
-	const long long g0 = (long long)blockIdx.x * GPB + t / NT, ng = (long long)gridDim.x * GPB;
-	/* the 8-register lazy accumulator while the register file allows (13 of them at NT = 8) */
-	using DotAcc = typename std::conditional<(NT <= 8 && sizeof(W) == 8), AccL, Acc>::type;
-	DotAcc a1[NT], a2[H];
+template <typename A, int MERS, int NT>
+struct DotState {
+	static constexpr int H = NT / 2 + 1, SLOTS = NT + H, WAVES = BLOCK / 64;
+	A a1[NT], a2[H];
+	u32 cnt;
+
+	__device__ __forceinline__ void init()
+	{
 #pragma unroll
-	for (int q = 0; q < NT; q++)
-		acc_zero(a1[q]);
+		for (int q = 0; q < NT; q++)
+			acc_zero(a1[q]);
 #pragma unroll
-	for (int q = 0; q < H; q++)
-		acc_zero(a2[q]);
-	u32 cnt = 0;
-	for (long long r = g0; r < rows; r += ng) {
-		const u64 vi = V[(size_t)r * NT + i], ai = AV[(size_t)r * NT + i];
+		for (int q = 0; q < H; q++)
+			acc_zero(a2[q]);
+		cnt = 0;
+	}
+
+	/* one block row: vi = v[r,i], ai = Av[r,i]; gbase = first lane of the group within the wavefront */
+	__device__ __forceinline__ void row(u64 vi, u64 ai, int i, int gbase, const ModP &m)
+	{
 #pragma unroll
 		for (int q = 0; q < NT; q++) {
 			const u64 aq = q == 0 ? ai : shfl64(ai, gbase + ((i + q) & (NT - 1)));
@@ -254,32 +275,163 @@ k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long ro
 				acc_set(a2[q], acc_reduce<MERS>(a2[q], m));
 		}
 	}
-	/* wave: sum the 64/NT groups; block: sum the waves through LDS */
+
+	/* wave: sum the 64/NT groups; block: sum the waves through LDS; one partial row per block.
+	 * Must be reached by every thread of the block. */
+	__device__ __forceinline__ void finish(u64 (*red)[SLOTS][NT], u64 *__restrict__ partial, const ModP &m)
+	{
+		const int t = threadIdx.x, lane = t & 63, i = t & (NT - 1);
 #pragma unroll
-	for (int q = 0; q < SLOTS; q++) {
-		u64 x = q < NT ? acc_reduce<MERS>(a1[q < NT ? q : 0], m) : acc_reduce<MERS>(a2[q < NT ? 0 : q - NT], m);
+		for (int q = 0; q < SLOTS; q++) {
+			u64 x = q < NT ? acc_reduce<MERS>(a1[q < NT ? q : 0], m) : acc_reduce<MERS>(a2[q < NT ? 0 : q - NT], m);
 #pragma unroll
-		for (int off = NT; off < 64; off <<= 1)
-			x = addmod(x, shfl_xor64(x, off), m.p);
-		if (lane < NT)
-			red[t >> 6][q][i] = x;
-	}
-	__syncthreads();
-	for (int e = t; e < SLOTS * NT; e += BLOCK) {
-		const int q = e / NT, ii = e % NT;
-		u64 x = 0;
+			for (int off = NT; off < 64; off <<= 1)
+				x = addmod(x, shfl_xor64(x, off), m.p);
+			if (lane < NT)
+				red[t >> 6][q][i] = x;
+		}
+		__syncthreads();
+		for (int e = t; e < SLOTS * NT; e += BLOCK) {
+			const int q = e / NT, ii = e % NT;
+			u64 x = 0;
 #pragma unroll
-		for (int w = 0; w < WAVES; w++)
-			x = addmod(x, red[w][q][ii], m.p);
-		u64 *out = partial + (size_t)blockIdx.x * 2 * NT * NT;
-		if (q < NT) {
-			out[ii * NT + ((ii + q) & (NT - 1))] = x;
-		} else {
-			const int jj = (ii + (q - NT)) & (NT - 1);
-			out[NT * NT + ii * NT + jj] = x;
-			out[NT * NT + jj * NT + ii] = x;
+			for (int w = 0; w < WAVES; w++)
+				x = addmod(x, red[w][q][ii], m.p);
+			u64 *out = partial + (size_t)blockIdx.x * 2 * NT * NT;
+			if (q < NT) {
+				out[ii * NT + ((ii + q) & (NT - 1))] = x;
+			} else {
+				const int jj = (ii + (q - NT)) & (NT - 1);
+				out[NT * NT + ii * NT + jj] = x;
+				out[NT * NT + jj * NT + ii] = x;
+			}
 		}
 	}
+};
+
+template <typename W, int MERS, int NT>
+__global__ void __launch_bounds__(BLOCK)
+k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long rows, ModP m,
+		 u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	/* the 8-register lazy accumulator while the register file allows (13 of them at NT = 8) */
+	using DotAcc = typename std::conditional<(NT <= 8 && sizeof(W) == 8), AccL, Acc>::type;
+	using DS = DotState<DotAcc, MERS, NT>;
+	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
+	constexpr int GPB = BLOCK / NT;
+	const int t = threadIdx.x, lane = t & 63, i = t & (NT - 1), gbase = lane - i;
+	const long long g0 = (long long)blockIdx.x * GPB + t / NT, ng = (long long)gridDim.x * GPB;
+	DS ds;
+	ds.init();
+	for (long long r = g0; r < rows; r += ng)
+		ds.row(V[(size_t)r * NT + i], AV[(size_t)r * NT + i], i, gbase, m);
+	ds.finish(red, partial, m);
+}
+
+/*
+ * Second SpMV of an iteration (Av = M tmp, sequential/lanczos_modp.c:636) with block_dot_products (:640) as its
+ * epilogue: the lane that has just produced Av[r,i] loads v[r,i] and feeds both products.  The SpMV is bound by
+ * the gather request rate and leaves the VALU idle ~90 % of the time, so the n x n work is free here and the
+ * separate pass over v and Av (2*N*n*w bytes) disappears.  n = NT = G in {1,2,4,8,16}.
+ */
+template <typename W, int MERS, int NT>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
+	   const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd, long long rows, ModP m,
+	   u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	using DS = DotState<Acc, MERS, NT>;
+	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
+	const int t = threadIdx.x, lane = t & (NT - 1), gbase = (t & 63) - lane;
+	const long long g0 = ((long long)blockIdx.x * BLOCK + t) / NT;
+	const long long ng = (long long)gridDim.x * (BLOCK / NT);
+	DS ds;
+	ds.init();
+	for (long long r = g0; r < rows; r += ng) {
+		u32 k = rp[r];
+		const u32 e = rp[r + 1];
+		const u64 vi = Vd[(size_t)r * NT + lane];
+		Acc acc;
+		acc_zero(acc);
+		if (va) {
+			for (; k + 4 <= e; k += 4) {
+				const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
+				const u32 a0 = va[k], a1 = va[k + 1], a2 = va[k + 2], a3 = va[k + 3];
+				const W x0 = X[(size_t)c0 * NT + lane], x1 = X[(size_t)c1 * NT + lane];
+				const W x2 = X[(size_t)c2 * NT + lane], x3 = X[(size_t)c3 * NT + lane];
+				acc_mac32(acc, a0, x0);
+				acc_mac32(acc, a1, x1);
+				acc_mac32(acc, a2, x2);
+				acc_mac32(acc, a3, x3);
+			}
+			for (; k < e; k++)
+				acc_mac32(acc, va[k], X[(size_t)ci[k] * NT + lane]);
+		} else {
+			for (; k + 4 <= e; k += 4) {
+				const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
+				const W x0 = X[(size_t)c0 * NT + lane], x1 = X[(size_t)c1 * NT + lane];
+				const W x2 = X[(size_t)c2 * NT + lane], x3 = X[(size_t)c3 * NT + lane];
+				acc_add(acc, x0);
+				acc_add(acc, x1);
+				acc_add(acc, x2);
+				acc_add(acc, x3);
+			}
+			for (; k < e; k++)
+				acc_add(acc, X[(size_t)ci[k] * NT + lane]);
+		}
+		const u64 y = acc_reduce<MERS>(acc, m);
+		Y[(size_t)r * NT + lane] = (W)y;
+		ds.row(vi, y, lane, gbase, m);
+	}
+	ds.finish(red, partial, m);
+}
+
+template <typename W, int MERS>
+static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, u64 *partial,
+				    int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
+{
+	const long long gpb = BLOCK / c.n;
+	long long blocks = (A.rows + gpb - 1) / gpb;
+	/* the accumulators cost registers: 4 resident blocks per CU at n = 8 (3 at n = 16), so size the grid for that */
+	const long long per_cu = c.n >= 16 ? 3 : (c.n >= 8 ? 4 : 6);
+	const long long cap = (long long)c.num_cu * per_cu < max_blocks ? (long long)c.num_cu * per_cu : max_blocks;
+	blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+	*nblocks = (int)blocks;
+#define SPMV_DOT(NN)                                                                                                \
+	case NN:                                                                                                    \
+		hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
+				   A.val, X, Y, Vd, (long long)A.rows, c.m, partial, ctl);                           \
+		break;
+	switch (c.n) {
+		SPMV_DOT(1)
+		SPMV_DOT(2)
+		SPMV_DOT(4)
+		SPMV_DOT(8)
+		SPMV_DOT(16)
+	default:
+		return hipErrorInvalidValue;
+	}
+#undef SPMV_DOT
+	return hipGetLastError();
+}
+
+bool spmv_dot_supported(const KernelCfg &c)
+{
+	return c.n == 1 || c.n == 2 || c.n == 4 || c.n == 8 || c.n == 16;
+}
+
+hipError_t launch_spmv_dot(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const void *Vd, u64 *partial,
+			   int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
+{
+	if (c.word == 4)
+		return c.mers == 31 ? spmv_dot_dispatch<u32, 31>(c, A, (const u32 *)X, (u32 *)Y, (const u32 *)Vd, partial, max_blocks, nblocks, ctl, s)
+				    : spmv_dot_dispatch<u32, 0>(c, A, (const u32 *)X, (u32 *)Y, (const u32 *)Vd, partial, max_blocks, nblocks, ctl, s);
+	return c.mers == 61 ? spmv_dot_dispatch<u64, 61>(c, A, (const u64 *)X, (u64 *)Y, (const u64 *)Vd, partial, max_blocks, nblocks, ctl, s)
+			    : spmv_dot_dispatch<u64, 0>(c, A, (const u64 *)X, (u64 *)Y, (const u64 *)Vd, partial, max_blocks, nblocks, ctl, s);
 }
 
 template <typename W, int MERS>

@@ -474,6 +474,110 @@ int blz_save_block(const char *path, int64_t nrows, int n, const uint64_t *v)
 	return BLZ_OK;
 }
 
+/* ------------------------------------------------------------------------ kernel checker */
+
+int blz_check_kernel(const char *matrix_path, const char *kernel_path, uint64_t prime, int right, int64_t *bad_row,
+		     int *bad_col)
+{
+	if (!matrix_path || !kernel_path || prime < 2)
+		return blz_fail(BLZ_EINVAL, "blz_check_kernel: bad argument");
+	blz_coo M;
+	int rc = blz_mm_load(matrix_path, prime, &M);
+	if (rc != BLZ_OK)
+		return rc;
+	const int64_t nrows = right ? M.ncols : M.nrows, ncols = right ? M.nrows : M.ncols;	/* :99-104 */
+
+	int fd = open(kernel_path, O_RDONLY);
+	struct stat st;
+	if (fd < 0 || fstat(fd, &st) != 0 || st.st_size == 0) {
+		if (fd >= 0)
+			close(fd);
+		blz_coo_free(&M);
+		return blz_fail(BLZ_EIO, "cannot open %s", kernel_path);
+	}
+	char *base = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (base == MAP_FAILED) {
+		blz_coo_free(&M);
+		return blz_fail(BLZ_EIO, "mmap %s: %s", kernel_path, strerror(errno));
+	}
+	cursor c = { base, base + st.st_size };
+	char line[1100];
+	long long nk = 0, n = 0;
+	uint64_t *x = NULL;
+	unsigned __int128 *y = NULL;
+	rc = BLZ_OK;
+	if (next_line(&c, line, sizeof line) || (rc = check_banner(line, 1)) != BLZ_OK) {
+		if (rc == BLZ_OK)
+			rc = blz_fail(BLZ_EFORMAT, "Could not process Matrix Market banner.");
+		goto done;
+	}
+	do {
+		if (next_line(&c, line, sizeof line)) {
+			rc = blz_fail(BLZ_EIO, "Cannot read kernel vector block size size");
+			goto done;
+		}
+	} while (line[0] == '%');
+	if (sscanf(line, "%lld %lld", &nk, &n) != 2 || n < 1) {
+		rc = blz_fail(BLZ_EIO, "Cannot read kernel vector block size size");
+		goto done;
+	}
+	if (nk != nrows) {
+		rc = blz_fail(BLZ_EINVAL, "dimension mismatch");
+		goto done;
+	}
+	x = malloc(sizeof *x * (size_t)(nrows * n + 1));
+	y = calloc((size_t)(ncols * n + 1), sizeof *y);
+	if (!x || !y) {
+		rc = blz_fail(BLZ_ENOMEM, "cannot allocate vector blocks");
+		goto done;
+	}
+	int any = 0;
+	for (long long k = 0; k < n; k++)		/* column-major, :146-153 */
+		for (long long i = 0; i < nrows; i++) {
+			long long w;
+			if (next_int(&c, &w)) {
+				rc = blz_fail(BLZ_EIO, "parse error entry %lld, %lld", i, k);
+				goto done;
+			}
+			/* a negative entry is the reference writer's "%d" of a u32 >= 2^31 */
+			const uint64_t word = w < 0 ? (uint64_t)(uint32_t)(int32_t)w : (uint64_t)w;
+			if (word >= prime) {
+				rc = blz_fail(BLZ_EINVAL, "entry %lld, %lld out of bound", i, k);
+				goto done;
+			}
+			x[i * n + k] = word;
+			any |= (word != 0);
+		}
+	if (!any) {
+		rc = 1;
+		goto done;
+	}
+	/* unreduced 128-bit sums, one reduction per word: value < 2^32, x < 2^62, nnz per column < 2^34 */
+	for (int64_t u = 0; u < M.nnz; u++) {
+		const int64_t i = right ? M.j[u] : M.i[u], j = right ? M.i[u] : M.j[u];
+		const uint64_t v = M.x[u];
+		for (long long k = 0; k < n; k++)
+			y[j * n + k] += (unsigned __int128)v * x[i * n + k];
+	}
+	for (int64_t j = 0; j < ncols && rc == BLZ_OK; j++)
+		for (long long k = 0; k < n; k++)
+			if (y[j * n + k] % prime != 0) {
+				if (bad_row)
+					*bad_row = j;
+				if (bad_col)
+					*bad_col = (int)k;
+				rc = 2;
+				break;
+			}
+done:
+	free(x);
+	free(y);
+	munmap(base, (size_t)st.st_size);
+	blz_coo_free(&M);
+	return rc;
+}
+
 /* -------------------------------------------------------------------------- checkpoints */
 
 typedef struct {

@@ -160,6 +160,16 @@ def save_block(path, nrows, n, v):
     check(lib().blz_save_block(path.encode(), C.c_int64(nrows), C.c_int(n), ptr(u64(v))))
 
 
+def check_kernel(matrix_path, kernel_path, prime, right=False):
+    """blz_check_kernel(): 0 OK, 1 all-zero kernel, 2 product not zero; raises on file/format errors."""
+    row, col = C.c_int64(0), C.c_int(0)
+    rc = lib().blz_check_kernel(matrix_path.encode(), kernel_path.encode(), C.c_uint64(prime), C.c_int(int(right)),
+                                C.byref(row), C.byref(col))
+    if rc < 0:
+        check(rc)
+    return rc
+
+
 def checkpoint_save(path, prime, n, right, nrows, iterations, v, p):
     check(lib().blz_checkpoint_save(path.encode(), C.c_uint64(prime), C.c_int(n), C.c_int(int(right)),
                                     C.c_int64(nrows), C.c_int64(iterations), ptr(u64(v)), ptr(u64(p))))

@@ -113,6 +113,15 @@ int blz_rng_fill(uint64_t *v, int64_t words, uint64_t prime);
  * cannot produce, are written as unsigned decimals). */
 int blz_save_block(const char *path, int64_t nrows, int n, const uint64_t *v);
 
+/* checker_modp.c:81-204 widened to u64 words (the reference's checker parses kernel entries with "%d" into a
+ * u32, so it cannot verify p > 2^31-1): loads the kernel block (MatrixMarket "array integer general", column-major,
+ * rows must equal the matrix's rows -- or columns with right!=0, :99-124), rejects entries >= prime (:150),
+ * computes y = x^T M (or M x) mod p and returns
+ *   0 = OK, 1 = kernel vectors are all zero (:155-161), 2 = y != 0 (:199-203); bad_row and bad_col locate the first
+ * non-zero word.  Negative returns are BLZ_E* errors (file, format, dimension mismatch). */
+int blz_check_kernel(const char *matrix_path, const char *kernel_path, uint64_t prime, int right,
+		     int64_t *bad_row, int *bad_col);
+
 /* Checkpoints (openMP/lanczos_modp.c:571-676, :933-940, :1013-1022).  blz_checkpoint_save writes
  * one binary file atomically (tmp + rename): v, p, iteration count, prime, n, shape.
  * The *_ref_text pair reads/writes the reference's five text files (v.txt tmp.txt Av.txt p.txt

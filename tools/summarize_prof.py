@@ -7,6 +7,7 @@ and the doubled value are both shown -- gathers of 32/64-byte rows are uncalibra
 """
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -30,6 +31,7 @@ if st:
     for r in csv.DictReader(open(st)):
         print(f"{short(r['Name']):70s} {r['Calls']:>7s} {float(r['AverageNs'])/1e3:10.1f} "
               f"{float(r['TotalDurationNs'])/1e6:10.2f} {float(r['Percentage']):6.1f}")
+traffic = defaultdict(dict)
 for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = find(sub, "counter_collection.csv")
     if not f:
@@ -46,3 +48,8 @@ for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         mean = tot / cnt
         extra = f"  (x2 for wide streams: {mean*2*1024/1e6:10.1f} MB)" if ctr == "FETCH_SIZE" else ""
         print(f"{k:70s} launches {cnt:6d}  mean {mean*1024/1e6:10.1f} MB{extra}")
+        traffic[k][ctr + "_bytes_per_launch"] = mean * 1024
+        traffic[k]["launches"] = cnt
+if traffic:
+    with open(os.path.join(root, "traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1, sort_keys=True)
