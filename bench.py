@@ -36,6 +36,10 @@ WORKLOADS = {
                    n=8, right=True, seed=0x52454C39, pattern=False),
     "relat8": dict(desc="JGD_Relat/relat8-shape synthetic", rows=345688, cols=12347, nnz=1334038, prime=P31,
                    n=4, right=False, seed=0x52454C38, pattern=False),
+    # config 5 is 50M x 50M, 2e9 nnz over 8 GPUs; this is one GPU's quarter-scale share of it (same density 40/row,
+    # all-ones pattern path, n=16, 128-byte block rows)
+    "synth5q": dict(desc="config-5-shape synthetic at 1/4 linear scale (all-ones pattern)", rows=12500000, cols=12500000,
+                    nnz=500000000, prime=P61, n=16, right=False, seed=0x53594E35, pattern=True),
     "tiny": dict(desc="tiny synthetic (self-test)", rows=20000, cols=15000, nnz=200000, prime=P61,
                  n=8, right=False, seed=0x54494E59, pattern=False),
 }

@@ -34,6 +34,96 @@ MODP_DEV u64 shfl_xor64(u64 x, int mask)
  * is reduced by one group of lanes: 128-bit unreduced sum of val*x per column, one reduction per
  * output word, one coalesced row store.  No atomics, deterministic.
  */
+
+/* acc += sum over entries [k, e) of val * X[col, xl]; `stride` = words per block row */
+template <typename W>
+MODP_DEV void spmv_accumulate(Acc &acc, u32 k, u32 e, const int *__restrict__ ci, const u32 *__restrict__ va,
+			      const W *__restrict__ X, int stride, int xl)
+{
+	if (va) {
+		for (; k + 4 <= e; k += 4) {
+			const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
+			const u32 a0 = va[k], a1 = va[k + 1], a2 = va[k + 2], a3 = va[k + 3];
+			const W x0 = X[(size_t)c0 * stride + xl], x1 = X[(size_t)c1 * stride + xl];
+			const W x2 = X[(size_t)c2 * stride + xl], x3 = X[(size_t)c3 * stride + xl];
+			acc_mac32(acc, a0, x0);
+			acc_mac32(acc, a1, x1);
+			acc_mac32(acc, a2, x2);
+			acc_mac32(acc, a3, x3);
+		}
+		for (; k < e; k++)
+			acc_mac32(acc, va[k], X[(size_t)ci[k] * stride + xl]);
+	} else {
+		for (; k + 4 <= e; k += 4) {
+			const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
+			const W x0 = X[(size_t)c0 * stride + xl], x1 = X[(size_t)c1 * stride + xl];
+			const W x2 = X[(size_t)c2 * stride + xl], x3 = X[(size_t)c3 * stride + xl];
+			acc_add(acc, x0);
+			acc_add(acc, x1);
+			acc_add(acc, x2);
+			acc_add(acc, x3);
+		}
+		for (; k < e; k++)
+			acc_add(acc, X[(size_t)ci[k] * stride + xl]);
+	}
+}
+
+MODP_DEV void acc_add_acc(Acc &a, u64 olo, u64 ohi)
+{
+	const u64 t = a.lo + olo;
+	a.hi += ohi + (t < olo);
+	a.lo = t;
+}
+
+/*
+ * Outlier rows.  A row with more than HEAVY_ROW entries would pin one lane group for the whole launch (real
+ * relation matrices do have a few very dense rows).  The group that meets one only records it; after the
+ * streaming loop the whole workgroup takes the recorded rows one at a time, every group summing a slice, and the
+ * slices are added through LDS.  Rows that do not fit the per-block list are processed in place.
+ */
+#define HEAVY_ROW 512u
+#define HEAVY_MAX 32
+
+struct HeavyList {
+	int cnt;
+	long long rows[HEAVY_MAX];
+};
+
+/* returns true when row r was put on the list (uniform over all lanes that share the row) */
+MODP_DEV bool heavy_defer(HeavyList &hl, long long r, int lane, u32 part, int leader_lane)
+{
+	int idx = 0;
+	if (lane == 0 && part == 0) {
+		idx = atomicAdd(&hl.cnt, 1);
+		if (idx < HEAVY_MAX)
+			hl.rows[idx] = r;
+	}
+	idx = __shfl(idx, leader_lane, 64);
+	return idx < HEAVY_MAX;
+}
+
+/* all threads of the block: sum row r over BLOCK/G slices; group 0 returns the 128-bit total */
+template <typename W, int G>
+MODP_DEV Acc heavy_row_sum(long long r, const u32 *__restrict__ rp, const int *__restrict__ ci,
+			   const u32 *__restrict__ va, const W *__restrict__ X, int stride, int xl, Acc (*slices)[G])
+{
+	constexpr int GPB = BLOCK / G;
+	const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+	const u32 k0 = rp[r], e0 = rp[r + 1];
+	const u32 per = (e0 - k0 + GPB - 1) / GPB;
+	const u32 lo = k0 + (u32)grp * per;
+	Acc acc;
+	acc_zero(acc);
+	spmv_accumulate<W>(acc, lo < e0 ? lo : e0, (lo + per) < e0 ? (lo + per) : e0, ci, va, X, stride, xl);
+	slices[grp][lane] = acc;
+	__syncthreads();
+	if (grp == 0)
+		for (int g = 1; g < GPB; g++)
+			acc_add_acc(acc, slices[g][lane].lo, slices[g][lane].hi);
+	__syncthreads();
+	return acc;
+}
+
 template <typename W, int G, int MERS>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
@@ -42,6 +132,11 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 {
 	if (ctl->stop)
 		return;
+	__shared__ HeavyList hl;
+	__shared__ Acc slices[BLOCK / G][G];
+	if (threadIdx.x == 0)
+		hl.cnt = 0;
+	__syncthreads();
 	const int lane = threadIdx.x & (G - 1);
 	const int xl = lane < n ? lane : 0;
 	/* 2^split_log2 adjacent groups of one wavefront share a row (few, long rows: keeps every CU busy and
@@ -50,8 +145,11 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 	const long long g0 = gid >> split_log2;
 	const u32 part = (u32)gid & ((1u << split_log2) - 1u);
 	const long long ng = ((long long)gridDim.x * (BLOCK / G)) >> split_log2;
+	const int leader = (threadIdx.x & 63) & ~((G << split_log2) - 1);
 	for (long long r = g0; r < rows; r += ng) {
 		u32 k = rp[r], e = rp[r + 1];
+		if (e - k > (HEAVY_ROW << split_log2) && heavy_defer(hl, r, lane, part, leader))
+			continue;
 		if (split_log2) {
 			const u32 len = e - k, per = (len + (1u << split_log2) - 1u) >> split_log2;
 			const u32 lo = k + part * per;
@@ -60,39 +158,18 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 		}
 		Acc acc;
 		acc_zero(acc);
-		if (va) {
-			for (; k + 4 <= e; k += 4) {
-				const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
-				const u32 a0 = va[k], a1 = va[k + 1], a2 = va[k + 2], a3 = va[k + 3];
-				const W x0 = X[(size_t)c0 * n + xl], x1 = X[(size_t)c1 * n + xl];
-				const W x2 = X[(size_t)c2 * n + xl], x3 = X[(size_t)c3 * n + xl];
-				acc_mac32(acc, a0, x0);
-				acc_mac32(acc, a1, x1);
-				acc_mac32(acc, a2, x2);
-				acc_mac32(acc, a3, x3);
-			}
-			for (; k < e; k++)
-				acc_mac32(acc, va[k], X[(size_t)ci[k] * n + xl]);
-		} else {
-			for (; k + 4 <= e; k += 4) {
-				const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
-				const W x0 = X[(size_t)c0 * n + xl], x1 = X[(size_t)c1 * n + xl];
-				const W x2 = X[(size_t)c2 * n + xl], x3 = X[(size_t)c3 * n + xl];
-				acc_add(acc, x0);
-				acc_add(acc, x1);
-				acc_add(acc, x2);
-				acc_add(acc, x3);
-			}
-			for (; k < e; k++)
-				acc_add(acc, X[(size_t)ci[k] * n + xl]);
-		}
-		for (int off = G; off < (G << split_log2); off <<= 1) {
-			const u64 olo = shfl_xor64(acc.lo, off), ohi = shfl_xor64(acc.hi, off);
-			const u64 t = acc.lo + olo;
-			acc.hi += ohi + (t < olo);
-			acc.lo = t;
-		}
+		spmv_accumulate<W>(acc, k, e, ci, va, X, n, xl);
+		for (int off = G; off < (G << split_log2); off <<= 1)
+			acc_add_acc(acc, shfl_xor64(acc.lo, off), shfl_xor64(acc.hi, off));
 		if (lane < n && part == 0)
+			Y[(size_t)r * n + lane] = (W)acc_reduce<MERS>(acc, m);
+	}
+	__syncthreads();
+	const int nh = hl.cnt < HEAVY_MAX ? hl.cnt : HEAVY_MAX;
+	for (int h = 0; h < nh; h++) {
+		const long long r = hl.rows[h];
+		const Acc acc = heavy_row_sum<W, G>(r, rp, ci, va, X, n, xl, slices);
+		if (threadIdx.x < G && lane < n)
 			Y[(size_t)r * n + lane] = (W)acc_reduce<MERS>(acc, m);
 	}
 }
@@ -346,46 +423,38 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 		return;
 	using DS = DotState<Acc, MERS, NT>;
 	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
+	__shared__ HeavyList hl;
+	__shared__ Acc slices[BLOCK / NT][NT];
+	if (threadIdx.x == 0)
+		hl.cnt = 0;
+	__syncthreads();
 	const int t = threadIdx.x, lane = t & (NT - 1), gbase = (t & 63) - lane;
 	const long long g0 = ((long long)blockIdx.x * BLOCK + t) / NT;
 	const long long ng = (long long)gridDim.x * (BLOCK / NT);
 	DS ds;
 	ds.init();
 	for (long long r = g0; r < rows; r += ng) {
-		u32 k = rp[r];
-		const u32 e = rp[r + 1];
+		const u32 k = rp[r], e = rp[r + 1];
+		if (e - k > HEAVY_ROW && heavy_defer(hl, r, lane, 0u, gbase))
+			continue;
 		const u64 vi = Vd[(size_t)r * NT + lane];
 		Acc acc;
 		acc_zero(acc);
-		if (va) {
-			for (; k + 4 <= e; k += 4) {
-				const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
-				const u32 a0 = va[k], a1 = va[k + 1], a2 = va[k + 2], a3 = va[k + 3];
-				const W x0 = X[(size_t)c0 * NT + lane], x1 = X[(size_t)c1 * NT + lane];
-				const W x2 = X[(size_t)c2 * NT + lane], x3 = X[(size_t)c3 * NT + lane];
-				acc_mac32(acc, a0, x0);
-				acc_mac32(acc, a1, x1);
-				acc_mac32(acc, a2, x2);
-				acc_mac32(acc, a3, x3);
-			}
-			for (; k < e; k++)
-				acc_mac32(acc, va[k], X[(size_t)ci[k] * NT + lane]);
-		} else {
-			for (; k + 4 <= e; k += 4) {
-				const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
-				const W x0 = X[(size_t)c0 * NT + lane], x1 = X[(size_t)c1 * NT + lane];
-				const W x2 = X[(size_t)c2 * NT + lane], x3 = X[(size_t)c3 * NT + lane];
-				acc_add(acc, x0);
-				acc_add(acc, x1);
-				acc_add(acc, x2);
-				acc_add(acc, x3);
-			}
-			for (; k < e; k++)
-				acc_add(acc, X[(size_t)ci[k] * NT + lane]);
-		}
+		spmv_accumulate<W>(acc, k, e, ci, va, X, NT, lane);
 		const u64 y = acc_reduce<MERS>(acc, m);
 		Y[(size_t)r * NT + lane] = (W)y;
 		ds.row(vi, y, lane, gbase, m);
+	}
+	__syncthreads();
+	const int nh = hl.cnt < HEAVY_MAX ? hl.cnt : HEAVY_MAX;
+	for (int h = 0; h < nh; h++) {
+		const long long r = hl.rows[h];
+		const Acc acc = heavy_row_sum<W, NT>(r, rp, ci, va, X, NT, lane, slices);
+		if (t < NT) {
+			const u64 y = acc_reduce<MERS>(acc, m);
+			Y[(size_t)r * NT + lane] = (W)y;
+			ds.row(Vd[(size_t)r * NT + lane], y, lane, gbase, m);
+		}
 	}
 	ds.finish(red, partial, m);
 }

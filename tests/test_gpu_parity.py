@@ -200,3 +200,27 @@ def test_heavy_rows_do_not_overflow():
         ctx.set_block(blz.V, vin)
         ctx.spmv(True, blz.V, blz.TMP)
         assert np.array_equal(ctx.get_block(blz.TMP), orc.spmv(as_orc(M), vin, True, n, p))
+
+
+@pytest.mark.parametrize("n,p", [(8, P61), (4, 2147483647), (16, 1073741789), (3, P61)])
+def test_outlier_rows_are_handled_by_the_whole_workgroup(n, p):
+    """A few very dense rows and columns among short ones (the shape of real relation matrices): rows above HEAVY_ROW
+    entries are deferred and summed by the whole workgroup; more of them than the per-block list holds (100 adjacent
+    rows of 600) fall back to in-place processing.  Both orientations, through a whole solve."""
+    rng = np.random.default_rng(11)
+    nr, nc = 6000, 5000
+    ii, jj = [], []
+    for r in range(nr):
+        k = 600 if r < 100 else (20000 if r in (777, 4242) else (3000 if r % 1500 == 7 else 4))
+        cols = rng.choice(nc, size=min(k, nc), replace=False) if k < nc else np.arange(nc)
+        ii.append(np.full(len(cols), r, dtype=np.int32))
+        jj.append(cols.astype(np.int32))
+    ii, jj = np.concatenate(ii), np.concatenate(jj)
+    jj[::97] = 13                                        # a dense column too (duplicates within a row are legal)
+    xx = rng.choice(np.array([1, 2, 3, 2 ** 32 - 1, 2 ** 32 - 2], dtype=np.uint64), size=len(ii)) % p
+    M = blz.Matrix(nr, nc, ii, jj, xx.astype(np.uint32))
+    for right in (False, True):
+        want = orc.block_lanczos(as_orc(M), n, p, right=right, stop_after=3)
+        got = blz.solve(M, p, n, right=right, stop_after=3, batch=3)
+        assert got["iterations"] == 3
+        assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])

@@ -68,7 +68,7 @@ static void run_alu(const char *name, u64 *out, int ncu)
 }
 
 // Each group of RW lanes gathers random (8*RW)-byte rows of a table; `U` independent loads in flight per lane.
-template <int U, int RW = 8>
+template <int U, int RW = 8, int POLICY = 0>
 __global__ void __launch_bounds__(256) k_gather(const u64 *__restrict__ table, const int *__restrict__ idx, long long count, u64 *out)
 {
 	const int lane = threadIdx.x & (RW - 1);
@@ -80,29 +80,29 @@ __global__ void __launch_bounds__(256) k_gather(const u64 *__restrict__ table, c
 #pragma unroll
 		for (int j = 0; j < U; j++) c[j] = idx[k + j];
 #pragma unroll
-		for (int j = 0; j < U; j++) x[j] = table[(size_t)c[j] * RW + lane];
+		for (int j = 0; j < U; j++) x[j] = POLICY == 1 ? __builtin_nontemporal_load(&table[(size_t)c[j] * RW + lane]) : (POLICY == 2 ? __hip_atomic_load(&table[(size_t)c[j] * RW + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : table[(size_t)c[j] * RW + lane]);
 #pragma unroll
 		for (int j = 0; j < U; j++) acc += x[j];
 	}
 	if (acc == 0x1234567) out[0] = acc;
 }
 
-template <int U, int RW = 8>
+template <int U, int RW = 8, int POLICY = 0>
 static void run_gather(const u64 *table, const int *idx, long long count, u64 *out, int ncu, double table_mb, int blocks_per_cu)
 {
 	hipEvent_t e0, e1;
 	CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
 	const int blocks = ncu * blocks_per_cu;
-	hipLaunchKernelGGL((k_gather<U, RW>), dim3(blocks), dim3(256), 0, 0, table, idx, count, out);
+	hipLaunchKernelGGL((k_gather<U, RW, POLICY>), dim3(blocks), dim3(256), 0, 0, table, idx, count, out);
 	CHK(hipDeviceSynchronize());
 	CHK(hipEventRecord(e0));
-	hipLaunchKernelGGL((k_gather<U, RW>), dim3(blocks), dim3(256), 0, 0, table, idx, count, out);
+	hipLaunchKernelGGL((k_gather<U, RW, POLICY>), dim3(blocks), dim3(256), 0, 0, table, idx, count, out);
 	CHK(hipEventRecord(e1));
 	CHK(hipEventSynchronize(e1));
 	float ms;
 	CHK(hipEventElapsedTime(&ms, e0, e1));
-	printf("gather %3dB rows  table %7.1f MB  in-flight/lane %2d  blocks/CU %d : %8.3f ms  %8.1f GB/s gathered, %6.1f G rows/s (+%.1f GB/s index stream)\n",
-	       RW * 8, table_mb, U, blocks_per_cu, ms, count * 8.0 * RW / ms / 1e6, count / ms / 1e6, count * 4.0 / ms / 1e6);
+	printf("gather[policy %d] %3dB rows  table %7.1f MB  in-flight/lane %2d  blocks/CU %d : %8.3f ms  %8.1f GB/s gathered, %6.1f G rows/s (+%.1f GB/s index stream)\n",
+	       POLICY, RW * 8, table_mb, U, blocks_per_cu, ms, count * 8.0 * RW / ms / 1e6, count / ms / 1e6, count * 4.0 / ms / 1e6);
 }
 
 int main()
@@ -142,6 +142,10 @@ int main()
 		if (mb == 125.0) {
 			run_gather<4>(table, idx, count, out, ncu, mb, 8);
 			run_gather<16>(table, idx, count, out, ncu, mb, 8);
+			run_gather<8, 8, 1>(table, idx, count, out, ncu, mb, 8);	// nontemporal loads
+			run_gather<8, 8, 2>(table, idx, count, out, ncu, mb, 8);	// sc1 (agent-scope relaxed atomic) loads
+			run_gather<8, 8, 0>(table, idx, count, out, ncu, mb, 4);
+			run_gather<8, 8, 1>(table, idx, count, out, ncu, mb, 4);
 			// row size: 32-byte and 128-byte rows out of the same bytes (indices rescaled on the fly by the table stride)
 			for (long long k = 0; k < count; k++) h[k] = h[k] / 2;
 			CHK(hipMemcpy(idx, h.data(), count * 4, hipMemcpyHostToDevice));
