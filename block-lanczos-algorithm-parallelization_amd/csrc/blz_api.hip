@@ -108,6 +108,9 @@ struct blz_ctx {
 	DevCtl *ctl = nullptr;
 	DevCtl host_ctl{};
 	ncclComm_t comm = nullptr;
+	/* perm[side][original row] = row in the solver's numbering (empty = identity); inv is the inverse */
+	std::vector<int32_t> perm[2], inv[2];
+	bool reorder = true;		/* BLZ_NO_REORDER=1 keeps the file's numbering */
 	bool fuse_dot = true;		/* BLZ_NO_FUSE=1 keeps block_dot as its own kernel (A/B measurements) */
 	bool external_exchange = false;
 	bool force_comm = false;	/* BLZ_FORCE_COMM=1: issue the collectives even on one rank (plumbing test) */
@@ -195,6 +198,8 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	if (const char *bp = getenv("BLZ_SPMV_BLOCKS_PER_CU"))
 		if (atoi(bp) >= 1 && atoi(bp) <= 64)
 			c->cfg.spmv_blocks_per_cu = atoi(bp);
+	const char *nr = getenv("BLZ_NO_REORDER");
+	c->reorder = !(nr && nr[0] == '1');
 	const char *nf = getenv("BLZ_NO_FUSE");
 	c->fuse_dot = !(nf && nf[0] == '1');
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -280,7 +285,35 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 	blz_csr slabs[2];
 	c->bounds[0].assign((size_t)nranks + 1, 0);
 	c->bounds[1].assign((size_t)nranks + 1, 0);
-	int rc = blz_shard_matrix(M, right, rank, nranks, slabs, c->bounds[0].data(), c->bounds[1].data(), c->stride);
+	int rc;
+	for (int sd = 0; sd < 2; sd++) {
+		c->perm[sd].clear();
+		c->inv[sd].clear();
+	}
+	if (c->reorder && M->nnz > 0) {
+		/* renumber both index spaces for locality, then shard the renumbered matrix */
+		const int rs = right ? 1 : 0, cs = 1 - rs;	/* side of M's rows / columns */
+		c->perm[rs].resize((size_t)M->nrows);
+		c->perm[cs].resize((size_t)M->ncols);
+		if ((rc = blz_reorder(M, c->perm[rs].data(), c->perm[cs].data())) != BLZ_OK)
+			return rc;
+		for (int sd = 0; sd < 2; sd++) {
+			c->inv[sd].resize(c->perm[sd].size());
+			for (size_t r = 0; r < c->perm[sd].size(); r++)
+				c->inv[sd][(size_t)c->perm[sd][r]] = (int32_t)r;
+		}
+		std::vector<int32_t> ni((size_t)M->nnz), nj((size_t)M->nnz);
+		for (int64_t k = 0; k < M->nnz; k++) {
+			ni[(size_t)k] = c->perm[rs][(size_t)M->i[k]];
+			nj[(size_t)k] = c->perm[cs][(size_t)M->j[k]];
+		}
+		blz_coo R = *M;
+		R.i = ni.data();
+		R.j = nj.data();
+		rc = blz_shard_matrix(&R, right, rank, nranks, slabs, c->bounds[0].data(), c->bounds[1].data(), c->stride);
+	} else {
+		rc = blz_shard_matrix(M, right, rank, nranks, slabs, c->bounds[0].data(), c->bounds[1].data(), c->stride);
+	}
 	if (rc != BLZ_OK)
 		return rc;
 	for (int sd = 0; sd < 2; sd++) {
@@ -362,6 +395,19 @@ static int get_words(blz_ctx *c, uint64_t *dst, const void *src, int64_t words)
 		HIPCHK(hipSetDevice((c)->device));                                      \
 	} while (0)
 
+/* host block in ORIGINAL numbering -> one contiguous array in the solver's numbering (and back) */
+static void to_solver_order(const blz_ctx *c, int sd, const uint64_t *host, uint64_t *out)
+{
+	const int n = c->cfg.n;
+	const int64_t rows = c->glob_rows[sd];
+	if (c->perm[sd].empty()) {
+		memcpy(out, host, (size_t)rows * n * sizeof(uint64_t));
+		return;
+	}
+	for (int64_t r = 0; r < rows; r++)
+		memcpy(out + (size_t)c->perm[sd][(size_t)r] * n, host + (size_t)r * n, (size_t)n * sizeof(uint64_t));
+}
+
 extern "C" int blz_set_block(blz_ctx *c, int block, const uint64_t *host)
 {
 	NEED_MATRIX(c);
@@ -369,10 +415,17 @@ extern "C" int blz_set_block(blz_ctx *c, int block, const uint64_t *host)
 		return blz_fail(BLZ_EINVAL, "blz_set_block: bad argument");
 	HIPCHK(hipStreamSynchronize(c->stream));
 	const int sd = side_of(block), n = c->cfg.n;
+	std::vector<uint64_t> tmp;
+	const uint64_t *src = host;
+	if (!c->perm[sd].empty()) {
+		tmp.resize((size_t)std::max<int64_t>(c->glob_rows[sd], 1) * n);
+		to_solver_order(c, sd, host, tmp.data());
+		src = tmp.data();
+	}
 	for (int g = 0; g < c->nranks; g++) {
 		const int64_t b0 = c->bounds[sd][g], cnt = c->bounds[sd][g + 1] - b0;
 		char *dst = (char *)c->blk[block] + (size_t)g * c->stride[sd] * n * c->cfg.word;
-		int rc = put_words(c, dst, host + b0 * n, cnt * n);
+		int rc = put_words(c, dst, src + b0 * n, cnt * n);
 		if (rc != BLZ_OK)
 			return rc;
 	}
@@ -386,7 +439,30 @@ extern "C" int blz_get_block(blz_ctx *c, int block, uint64_t *host)
 		return blz_fail(BLZ_EINVAL, "blz_get_block: bad argument");
 	HIPCHK(hipStreamSynchronize(c->stream));
 	const int sd = side_of(block), n = c->cfg.n;
-	return get_words(c, host + c->first[sd] * n, slab_ptr(c, block), c->count[sd] * n);
+	if (c->perm[sd].empty())
+		return get_words(c, host + c->first[sd] * n, slab_ptr(c, block), c->count[sd] * n);
+	std::vector<uint64_t> tmp((size_t)std::max<int64_t>(c->count[sd], 1) * n);
+	int rc = get_words(c, tmp.data(), slab_ptr(c, block), c->count[sd] * n);
+	if (rc != BLZ_OK)
+		return rc;
+	for (int64_t q = 0; q < c->count[sd]; q++)
+		memcpy(host + (size_t)c->inv[sd][(size_t)(c->first[sd] + q)] * n, tmp.data() + (size_t)q * n,
+		       (size_t)n * sizeof(uint64_t));
+	return BLZ_OK;
+}
+
+extern "C" int blz_owner_of_row(const blz_ctx *c, int block, int64_t row)
+{
+	if (!c || !c->have_matrix || block < 0 || block > 3)
+		return -1;
+	const int sd = side_of(block);
+	if (row < 0 || row >= c->glob_rows[sd])
+		return -1;
+	const int64_t r = c->perm[sd].empty() ? row : c->perm[sd][(size_t)row];
+	int g = 0;
+	while (g + 1 < c->nranks && c->bounds[sd][g + 1] <= r)
+		g++;
+	return g;
 }
 
 static int small_off(const blz_ctx *c, int which, int *words)
@@ -436,16 +512,22 @@ extern "C" int blz_init_v(blz_ctx *c)
 		HIPCHK(hipMemset(c->blk[b], 0, c->blk_bytes));
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
 	c->host_ctl = DevCtl{};
-	/* :624-625: one sequential stream over the whole block; a rank keeps its rows. */
+	/* :624-625: one sequential stream over the whole block in ORIGINAL row order; a rank keeps the rows it owns. */
 	const int n = c->cfg.n;
-	const int64_t skip = c->first[0] * n, keep = c->count[0] * n;
+	const int64_t keep = c->count[0] * n, lo = c->first[0], hi = c->first[0] + c->count[0];
 	std::vector<uint64_t> mine((size_t)std::max<int64_t>(keep, 1));
 	uint64_t s[4];
 	blz_rng_seed(s);
-	for (int64_t k = 0; k < skip; k++)
-		(void)blz_rng_next(s);
-	for (int64_t k = 0; k < keep; k++)
-		mine[(size_t)k] = blz_rng_next(s) % c->prime;
+	for (int64_t r = 0; r < c->glob_rows[0]; r++) {
+		const int64_t nr = c->perm[0].empty() ? r : c->perm[0][(size_t)r];
+		if (nr >= lo && nr < hi) {
+			for (int l = 0; l < n; l++)
+				mine[(size_t)((nr - lo) * n + l)] = blz_rng_next(s) % c->prime;
+		} else {
+			for (int l = 0; l < n; l++)
+				(void)blz_rng_next(s);
+		}
+	}
 	return put_words(c, slab_ptr(c, BLZ_V), mine.data(), keep);
 }
 

@@ -364,6 +364,51 @@ void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t str
 	}
 }
 
+/* stable counting sort of `count` items by key in [0, nkeys]: perm[item] = new position */
+static int sort_by_key(const int32_t *key, int64_t count, int64_t nkeys, int32_t *perm)
+{
+	int64_t *start = calloc((size_t)nkeys + 2, sizeof *start);
+	if (!start)
+		return blz_fail(BLZ_ENOMEM, "blz_reorder: out of memory");
+	for (int64_t k = 0; k < count; k++)
+		start[key[k] + 1]++;
+	for (int64_t q = 0; q <= nkeys; q++)
+		start[q + 1] += start[q];
+	for (int64_t k = 0; k < count; k++)
+		perm[k] = (int32_t)start[key[k]]++;
+	free(start);
+	return BLZ_OK;
+}
+
+int blz_reorder(const blz_coo *M, int32_t *row_perm, int32_t *col_perm)
+{
+	if (!M || !row_perm || !col_perm)
+		return blz_fail(BLZ_EINVAL, "blz_reorder: bad argument");
+	int32_t *key = malloc(sizeof *key * (size_t)((M->nrows > M->ncols ? M->nrows : M->ncols) + 1));
+	if (!key)
+		return blz_fail(BLZ_ENOMEM, "blz_reorder: out of memory");
+	/* rows by smallest column (rows without entries last) */
+	for (int64_t r = 0; r < M->nrows; r++)
+		key[r] = (int32_t)M->ncols;
+	for (int64_t k = 0; k < M->nnz; k++)
+		if (M->j[k] < key[M->i[k]])
+			key[M->i[k]] = M->j[k];
+	int rc = sort_by_key(key, M->nrows, M->ncols, row_perm);
+	/* columns by smallest NEW row */
+	if (rc == BLZ_OK) {
+		for (int64_t c = 0; c < M->ncols; c++)
+			key[c] = (int32_t)M->nrows;
+		for (int64_t k = 0; k < M->nnz; k++) {
+			const int32_t nr = row_perm[M->i[k]];
+			if (nr < key[M->j[k]])
+				key[M->j[k]] = nr;
+		}
+		rc = sort_by_key(key, M->ncols, M->nrows, col_perm);
+	}
+	free(key);
+	return rc;
+}
+
 int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, blz_csr slabs[2], int64_t *bounds0,
 		     int64_t *bounds1, int64_t stride[2])
 {

@@ -144,6 +144,14 @@ def shard_matrix(M, right, rank, nranks):
     return dict(slabs=out, bounds=[list(b0), list(b1)], stride=list(stride))
 
 
+def reorder(M):
+    """blz_reorder(): (row_perm, col_perm), new index of every row / column of M."""
+    rp = np.zeros(M.nrows, dtype=np.int32)
+    cp = np.zeros(M.ncols, dtype=np.int32)
+    check(lib().blz_reorder(C.byref(M.c), rp.ctypes.data_as(C.POINTER(C.c_int32)), cp.ctypes.data_as(C.POINTER(C.c_int32))))
+    return rp, cp
+
+
 def rng_draws(count):
     s = (C.c_uint64 * 4)()
     lib().blz_rng_seed(s)
@@ -224,6 +232,9 @@ class Context:
         first = C.c_int64(0)
         cnt = int(lib().blz_local_rows(self.h, C.c_int(block), C.byref(first)))
         return int(first.value), cnt
+
+    def owner_of_row(self, block, row):
+        return int(lib().blz_owner_of_row(self.h, C.c_int(block), C.c_int64(row)))
 
     def init_v(self):
         check(lib().blz_init_v(self.h))

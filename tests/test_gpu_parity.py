@@ -224,3 +224,26 @@ def test_outlier_rows_are_handled_by_the_whole_workgroup(n, p):
         got = blz.solve(M, p, n, right=right, stop_after=3, batch=3)
         assert got["iterations"] == 3
         assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
+
+
+@pytest.mark.parametrize("name,p,n,right", [("rand3000x2000", P61, 8, False), ("rand300x200", 65537, 4, True),
+                                            ("quirks40x30", 1073741789, 2, False)])
+def test_results_do_not_depend_on_the_internal_renumbering(monkeypatch, name, p, n, right):
+    """The solver renumbers rows for locality (blz_reorder); with BLZ_NO_REORDER=1 it keeps the file's numbering.
+    Blocks cross the ABI in the original numbering either way and are bit-identical."""
+    M, Mo = load_both(name, p)
+    want = orc.block_lanczos(Mo, n, p, right=right, stop_after=9)
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BLZ_NO_REORDER", flag)
+        with blz.Context(p, n) as ctx:
+            ctx.set_matrix(M, right)
+            ctx.init_v()
+            assert np.array_equal(ctx.get_block(blz.V), orc.init_v(ctx.rows(blz.V), n, p))
+            ctx.iterate(want["iterations"])
+            assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
+            # set_block / get_block round trip in the original numbering
+            x = np.arange(ctx.rows(blz.TMP) * n, dtype=np.uint64) % p
+            ctx.set_block(blz.TMP, x)
+            assert np.array_equal(ctx.get_block(blz.TMP), x)
+            ctx.spmv(right, blz.TMP, blz.AV)
+            assert np.array_equal(ctx.get_block(blz.AV), orc.spmv(Mo, x, right, n, p))

@@ -29,10 +29,11 @@ def sharded_solve(M, p, n, right, world, max_iters):
             c.init_v()
 
         def gather(block):
+            # get_block writes only the rows a rank owns (original numbering; not contiguous once the solver has
+            # renumbered rows for locality), so the disjoint parts simply add up
             full = np.zeros(ctxs[0].rows(block) * n, dtype=np.uint64)
             for c in ctxs:
-                first, cnt = c.local_rows(block)
-                full[first * n:(first + cnt) * n] = c.get_block(block)[first * n:(first + cnt) * n]
+                full += c.get_block(block)
             return full
 
         its = 0
@@ -82,6 +83,22 @@ def test_rank_local_kernels_with_emulated_exchange(name, p, n, right, iters, wor
     assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
     if iters > 10 ** 8:
         assert np.array_equal(got["tmp"], want["tmp"])
+
+
+def test_every_row_has_exactly_one_owner():
+    M = blz.Matrix.load(os.path.join(GOLDEN, "rand300x200.mtx"), P61)
+    ctxs = [blz.Context(P61, 4) for _ in range(3)]
+    try:
+        for g, c in enumerate(ctxs):
+            c.set_matrix(M, False, g, 3)
+        for block, rows in ((blz.V, 300), (blz.TMP, 200)):
+            owners = [ctxs[0].owner_of_row(block, r) for r in range(rows)]
+            assert set(owners) <= {0, 1, 2} and all(ctxs[1].owner_of_row(block, r) == owners[r] for r in range(rows))
+            for g, c in enumerate(ctxs):
+                assert owners.count(g) == c.local_rows(block)[1]
+    finally:
+        for c in ctxs:
+            c.close()
 
 
 def test_multi_rank_context_without_communicator_fails_loudly():

@@ -138,3 +138,20 @@ def test_checkpoint_roundtrip_and_mismatch(tmp_path):
         blz.checkpoint_load(path, p, n, True, nrows)
     with pytest.raises(blz.BlzError):
         blz.checkpoint_load(path, 65537, n, False, nrows)
+
+
+@pytest.mark.parametrize("name", ["rand300x200", "wide120x260", "quirks40x30", "rand3000x2000"])
+def test_reorder_gives_permutations_sorted_by_smallest_neighbour(name):
+    M = blz.Matrix.load(os.path.join(GOLDEN, name + ".mtx"), 65537)
+    rp, cp = blz.reorder(M)
+    assert sorted(rp.tolist()) == list(range(M.nrows)) and sorted(cp.tolist()) == list(range(M.ncols))
+    mincol = np.full(M.nrows, M.ncols, dtype=np.int64)
+    np.minimum.at(mincol, M.i, M.j)
+    by_new = np.empty(M.nrows, dtype=np.int64)
+    by_new[rp] = mincol
+    assert (np.diff(by_new) >= 0).all()                      # rows in new order have non-decreasing smallest column
+    minrow = np.full(M.ncols, M.nrows, dtype=np.int64)
+    np.minimum.at(minrow, M.j, rp[M.i])
+    by_new = np.empty(M.ncols, dtype=np.int64)
+    by_new[cp] = minrow
+    assert (np.diff(by_new) >= 0).all()
