@@ -65,6 +65,12 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): RCCL and gloo print banners to fd 1 from native code, so fd 1 is
+    # pointed at stderr for the duration of the run and the result is written to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -79,7 +85,8 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("BLZ_BENCH_DIST") == "1":
+        # launched by torch.distributed.run (also with one process: the same code path as N > 1)
         import torch.distributed as dist
         dist.init_process_group(backend="gloo", init_method="env://")
     if blz.device_count() < 1:
@@ -93,7 +100,7 @@ def main():
     t_gen = time.time() - t0
 
     ctx = blz.Context(p, n, device=local_rank)
-    if world > 1:
+    if dist is not None:
         uid = [blz.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
@@ -260,7 +267,8 @@ def main():
 
     ctx.close()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
