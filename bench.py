@@ -144,18 +144,10 @@ def main():
     _, loc_v = ctx.local_rows(blz.V)
     _, loc_t = ctx.local_rows(blz.TMP)
     # per-rank algorithmic bytes of the two SpMV launches (X is read whole by every rank)
-    csr_first = M.csr(transpose=not right)   # tmp = (right ? M : M^T) v
-    csr_second = M.csr(transpose=right)
-    if world == 1:
-        nnz1 = nnz2 = M.nnz
-    else:
-        bd1, bd2 = csr_first["partition"][world], csr_second["partition"][world]
-        nnz1 = int(csr_first["row_ptr"][bd1[rank + 1]]) - int(csr_first["row_ptr"][bd1[rank]])
-        nnz2 = int(csr_second["row_ptr"][bd2[rank + 1]]) - int(csr_second["row_ptr"][bd2[rank]])
-    pattern = csr_first["val"] is None
+    nnz1, nnz2 = ctx.local_nnz(not right), ctx.local_nnz(right)   # tmp = (right ? M : M^T) v, then Av = the other one
+    pattern = bool((M.x == 1).all())
     bytes1 = spmv_alg_bytes(nnz1, loc_t, rows_v, n, word, pattern)
     bytes2 = spmv_alg_bytes(nnz2, loc_v, rows_t, n, word, pattern)
-    del csr_first, csr_second
     # roofline kernel = k_spmv, the first SpMV of every step (the second one carries block_dot as its epilogue and is
     # listed under "kernels"); HIP-event spans on the solver's stream, collected inside blz_iterate
     l1 = prof["spmv1"]["launches"]

@@ -357,6 +357,11 @@ extern "C" int64_t blz_local_rows(const blz_ctx *c, int block, int64_t *first)
 	return c->count[side_of(block)];
 }
 
+extern "C" int64_t blz_local_nnz(const blz_ctx *c, int transpose)
+{
+	return (c && c->have_matrix) ? c->csr[transpose ? 1 : 0].nnz : -1;
+}
+
 /* host u64 words -> device words of the context's width */
 static int put_words(blz_ctx *c, void *dst, const uint64_t *src, int64_t words)
 {

@@ -565,7 +565,17 @@ k_dot_finalize(const u64 *__restrict__ partial, int nblocks, int words, u64 p, u
 	if (e >= words)
 		return;
 	u64 s = 0;
-	for (int b = lane; b < nblocks; b += 64)
+	int b = lane;
+	for (; b + 7 * 64 < nblocks; b += 8 * 64) {	/* eight independent loads in flight, then the adds */
+		u64 x[8];
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			x[q] = partial[(size_t)(b + q * 64) * words + e];
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			s = addmod(s, x[q], p);
+	}
+	for (; b < nblocks; b += 64)
 		s = addmod(s, partial[(size_t)b * words + e], p);
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1)

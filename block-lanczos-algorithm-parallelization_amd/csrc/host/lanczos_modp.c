@@ -14,6 +14,7 @@
 #include <err.h>
 #include <getopt.h>
 #include <inttypes.h>
+#include <pthread.h>
 #include <stdbool.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -28,7 +29,7 @@ static long n = 1;
 static uint64_t prime;
 static char *matrix_filename, *kernel_filename;
 static bool right_kernel, checkpoints, load_checkpoint;
-static int stop_after = -1, checkpoint_timer = 60, device;
+static int stop_after = -1, checkpoint_timer = 60, device, gpus = 1;
 
 static double wtime(void)
 {
@@ -65,7 +66,9 @@ static void usage(char **argv)
 	printf("--stop-after N              stop the algorithm after N iterations\n");
 	printf("--checkpoint [cp]           make a checkpoint every cp seconds [default 60] (lanczos_modp.ckpt)\n");
 	printf("--load-checkpoint           restart from the checkpoint in the current directory\n");
-	printf("--device D                  HIP device to run on [default 0]\n");
+	printf("--device D                  first HIP device to run on [default 0]\n");
+	printf("--gpus G                    row-partition the matrix over G GPUs of this node (devices D..D+G-1), RCCL\n");
+	printf("                            all-gather of the block before each product [default 1]\n");
 	printf("\n");
 	printf("The --matrix and --prime arguments are required\n");
 	printf("The --stop-after and --output-file arguments mutually exclusive\n");
@@ -80,7 +83,7 @@ static void process_command_line_options(int argc, char **argv)
 		{"right", no_argument, NULL, 'r'}, {"left", no_argument, NULL, 'l'},
 		{"stop-after", required_argument, NULL, 's'}, {"checkpoint", optional_argument, NULL, 'c'},
 		{"load-checkpoint", no_argument, NULL, 'L'}, {"device", required_argument, NULL, 'd'},
-		{"help", no_argument, NULL, 'h'}, {NULL, 0, NULL, 0}
+		{"gpus", required_argument, NULL, 'g'}, {"help", no_argument, NULL, 'h'}, {NULL, 0, NULL, 0}
 	};
 	int ch;
 	while ((ch = getopt_long(argc, argv, "", longopts, NULL)) != -1) {
@@ -101,6 +104,7 @@ static void process_command_line_options(int argc, char **argv)
 			break;
 		case 'L': load_checkpoint = true; break;
 		case 'd': device = atoi(optarg); break;
+		case 'g': gpus = atoi(optarg); break;
 		case 'h': usage(argv); break;
 		default: errx(1, "Unknown option\n");
 		}
@@ -113,6 +117,8 @@ static void process_command_line_options(int argc, char **argv)
 		errx(1, "p is capped at 2**62 - 1.");
 	if (n < 1 || n > BLZ_MAX_N)
 		errx(1, "n must be between 1 and %d", BLZ_MAX_N);
+	if (gpus < 1 || gpus > 64)
+		errx(1, "--gpus must be between 1 and 64");
 }
 
 #define CHECK(call)                                                \
@@ -157,6 +163,91 @@ static void verbosity(void)
 	fflush(stdout);
 }
 
+/*
+ * One context per GPU, one host thread per context for the duration of each operation (the RCCL calls inside
+ * blz_comm_init / blz_iterate / blz_final_check must be entered by all ranks concurrently).  With --gpus 1 the
+ * operation runs on the calling thread.
+ */
+enum { OP_SETUP, OP_INIT, OP_SET_VP, OP_ITERATE, OP_GET, OP_FINAL, OP_DESTROY };
+
+static struct {
+	blz_ctx *ctx[64];
+	const blz_coo *M;
+	char uid[128];
+	int op, todo, block;
+	uint64_t *host, *host2;
+	int64_t its;
+	int done[64], stopped[64], nonzero[64], zero[64], rc[64];
+	float ms[64];
+	char err[64][512];
+} team;
+
+static void *team_worker(void *arg)
+{
+	const int g = (int)(intptr_t)arg;
+	int rc = BLZ_OK;
+	switch (team.op) {
+	case OP_SETUP:
+		rc = blz_create(&team.ctx[g], device + g, prime, (int)n);
+		if (rc == BLZ_OK && gpus > 1)
+			rc = blz_comm_init(team.ctx[g], team.uid, sizeof team.uid, g, gpus);
+		if (rc == BLZ_OK)
+			rc = blz_set_matrix(team.ctx[g], team.M, right_kernel, g, gpus);
+		break;
+	case OP_INIT:
+		rc = blz_init_v(team.ctx[g]);
+		break;
+	case OP_SET_VP:
+		rc = blz_set_block(team.ctx[g], BLZ_V, team.host);
+		if (rc == BLZ_OK)
+			rc = blz_set_block(team.ctx[g], BLZ_P, team.host2);
+		if (rc == BLZ_OK)
+			rc = blz_set_iterations(team.ctx[g], team.its);
+		break;
+	case OP_ITERATE:
+		rc = blz_iterate(team.ctx[g], team.todo, &team.done[g], &team.stopped[g], &team.ms[g]);
+		break;
+	case OP_GET:
+		rc = blz_get_block(team.ctx[g], team.block, team.host);	/* writes only the rows this rank owns */
+		break;
+	case OP_FINAL:
+		rc = blz_final_check(team.ctx[g], &team.nonzero[g], &team.zero[g]);
+		break;
+	case OP_DESTROY:
+		blz_destroy(team.ctx[g]);
+		break;
+	}
+	team.rc[g] = rc;
+	if (rc != BLZ_OK)
+		snprintf(team.err[g], sizeof team.err[g], "%s", blz_last_error());	/* blz_last_error is thread-local */
+	return NULL;
+}
+
+static void team_run(int op)
+{
+	team.op = op;
+	if (gpus == 1) {
+		team_worker((void *)(intptr_t)0);
+	} else {
+		pthread_t th[64];
+		for (int g = 0; g < gpus; g++)
+			if (pthread_create(&th[g], NULL, team_worker, (void *)(intptr_t)g))
+				errx(1, "cannot start a host thread for GPU %d", g);
+		for (int g = 0; g < gpus; g++)
+			pthread_join(th[g], NULL);
+	}
+	for (int g = 0; g < gpus; g++)
+		if (team.rc[g] != BLZ_OK)
+			errx(1, "GPU %d: %s", device + g, team.err[g]);
+}
+
+static void team_get(int block, uint64_t *host)
+{
+	team.block = block;
+	team.host = host;
+	team_run(OP_GET);
+}
+
 int main(int argc, char **argv)
 {
 	process_command_line_options(argc, argv);
@@ -170,9 +261,11 @@ int main(int argc, char **argv)
 		(long)M.nnz);
 	fprintf(stderr, "  - Read in %.2fs\n", wtime() - t_load);
 
-	blz_ctx *ctx;
-	CHECK(blz_create(&ctx, device, prime, (int)n));
-	CHECK(blz_set_matrix(ctx, &M, right_kernel, 0, 1));
+	if (gpus > 1)
+		CHECK(blz_comm_unique_id(team.uid, sizeof team.uid));
+	team.M = &M;
+	team_run(OP_SETUP);
+	blz_ctx *ctx = team.ctx[0];
 	const int64_t nrows = right_kernel ? M.ncols : M.nrows;
 	const int64_t ncols = right_kernel ? M.nrows : M.ncols;
 	blz_coo_free(&M);
@@ -195,14 +288,15 @@ int main(int argc, char **argv)
 			CHECK(blz_checkpoint_load("lanczos_modp.ckpt", prime, (int)n, right_kernel, nrows, &its, v, p));
 		else
 			CHECK(blz_checkpoint_load_ref_text(".", (int)n, nrows, ncols, &its, v, p));
-		CHECK(blz_init_v(ctx));
-		CHECK(blz_set_block(ctx, BLZ_V, v));
-		CHECK(blz_set_block(ctx, BLZ_P, p));
-		CHECK(blz_set_iterations(ctx, its));
+		team_run(OP_INIT);
+		team.host = v;
+		team.host2 = p;
+		team.its = its;
+		team_run(OP_SET_VP);
 		n_iterations = (int)its;
 		expected_iterations -= n_iterations;	/* openMP/lanczos_modp.c:971-972 */
 	} else {
-		CHECK(blz_init_v(ctx));
+		team_run(OP_INIT);
 	}
 	human_format(human, expected_iterations);
 	printf("  - Expecting %s iterations\n", human);
@@ -219,9 +313,11 @@ int main(int argc, char **argv)
 			if (todo > stop_after - n_iterations)
 				todo = stop_after - n_iterations;
 		}
-		int done = 0;
-		float ms = 0;
-		CHECK(blz_iterate(ctx, todo, &done, &stopped, &ms));
+		team.todo = todo;
+		team_run(OP_ITERATE);
+		const int done = team.done[0];
+		const float ms = team.ms[0];
+		stopped = team.stopped[0];
 		n_iterations += done;
 		verbosity();
 		/* keep the host out of the loop: grow the batch until one batch takes ~0.25 s */
@@ -229,15 +325,15 @@ int main(int argc, char **argv)
 			batch *= 2;
 		if (checkpoints && !stopped && (wtime() - checkpoint_start) >= checkpoint_timer) {
 			printf("\n");
-			CHECK(blz_get_block(ctx, BLZ_V, v));
-			CHECK(blz_get_block(ctx, BLZ_P, p));
+			team_get(BLZ_V, v);
+			team_get(BLZ_P, p);
 			printf("		>> Making a snapshot in lanczos_modp.ckpt (iteration %d)\n", n_iterations);
 			CHECK(blz_checkpoint_save("lanczos_modp.ckpt", prime, (int)n, right_kernel, nrows, n_iterations, v, p));
 			const char *ref = getenv("BLZ_REF_CHECKPOINT");
 			if (ref && ref[0] == '1' && prime < (1ull << 32)) {
 				uint64_t *t = calloc((size_t)(ncols * n + 1), sizeof *t), *a = calloc((size_t)(nrows * n + 1), sizeof *a);
-				CHECK(blz_get_block(ctx, BLZ_TMP, t));
-				CHECK(blz_get_block(ctx, BLZ_AV, a));
+				team_get(BLZ_TMP, t);
+				team_get(BLZ_AV, a);
 				CHECK(blz_checkpoint_save_ref_text(".", (int)n, nrows, ncols, n_iterations, start, wtime(), v, t, a, p));
 				free(t);
 				free(a);
@@ -248,8 +344,8 @@ int main(int argc, char **argv)
 	printf("\n");
 
 	if (stop_after < 0) {		/* final_check(), sequential/lanczos_modp.c:560-582 */
-		int nonzero = 0, zero = 0;
-		CHECK(blz_final_check(ctx, &nonzero, &zero));
+		team_run(OP_FINAL);
+		const int nonzero = team.nonzero[0], zero = team.zero[0];
 		printf("Final check:\n");
 		printf(nonzero ? "  - OK:    v != 0\n" : "  - KO:    v == 0\n");
 		printf(zero ? "  - OK: vt*M == 0\n" : "  - KO: vt*M != 0\n");
@@ -257,7 +353,7 @@ int main(int argc, char **argv)
 	printf("  - Terminated in %.1fs after %d iterations\n", wtime() - start, n_iterations);
 
 	if (kernel_filename) {
-		CHECK(blz_get_block(ctx, BLZ_V, v));
+		team_get(BLZ_V, v);
 		printf("Saving result in %s\n", kernel_filename);
 		CHECK(blz_save_block(kernel_filename, nrows, (int)n, v));
 	} else {
@@ -265,6 +361,6 @@ int main(int argc, char **argv)
 	}
 	free(v);
 	free(p);
-	blz_destroy(ctx);
+	team_run(OP_DESTROY);
 	exit(EXIT_SUCCESS);
 }

@@ -50,6 +50,7 @@ def lib():
         L.blz_rows.restype = C.c_int64
         L.blz_local_rows.restype = C.c_int64
         L.blz_iterations.restype = C.c_int64
+        L.blz_local_nnz.restype = C.c_int64
         L.blz_destroy.restype = None
         L.blz_coo_free.restype = None
         L.blz_csr_free.restype = None
@@ -232,6 +233,9 @@ class Context:
         first = C.c_int64(0)
         cnt = int(lib().blz_local_rows(self.h, C.c_int(block), C.byref(first)))
         return int(first.value), cnt
+
+    def local_nnz(self, transpose):
+        return int(lib().blz_local_nnz(self.h, C.c_int(int(transpose))))
 
     def owner_of_row(self, block, row):
         return int(lib().blz_owner_of_row(self.h, C.c_int(block), C.c_int64(row)))
