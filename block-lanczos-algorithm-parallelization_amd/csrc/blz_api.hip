@@ -111,6 +111,7 @@ struct blz_ctx {
 	/* perm[side][original row] = row in the solver's numbering (empty = identity); inv is the inverse */
 	std::vector<int32_t> perm[2], inv[2];
 	bool reorder = true;		/* BLZ_NO_REORDER=1 keeps the file's numbering */
+	bool pack = true;		/* BLZ_NO_PACK=1 keeps col_idx and val as two arrays */
 	bool fuse_dot = true;		/* BLZ_NO_FUSE=1 keeps block_dot as its own kernel (A/B measurements) */
 	bool external_exchange = false;
 	bool force_comm = false;	/* BLZ_FORCE_COMM=1: issue the collectives even on one rank (plumbing test) */
@@ -157,6 +158,7 @@ static void free_csr(DevCsr &A)
 	if (A.row_ptr) hipFree(A.row_ptr);
 	if (A.col_idx) hipFree(A.col_idx);
 	if (A.val) hipFree(A.val);
+	if (A.palette) hipFree(A.palette);
 	A = DevCsr{};
 }
 
@@ -198,6 +200,8 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	if (const char *bp = getenv("BLZ_SPMV_BLOCKS_PER_CU"))
 		if (atoi(bp) >= 1 && atoi(bp) <= 64)
 			c->cfg.spmv_blocks_per_cu = atoi(bp);
+	const char *np = getenv("BLZ_NO_PACK");
+	c->pack = !(np && np[0] == '1');
 	const char *nr = getenv("BLZ_NO_REORDER");
 	c->reorder = !(nr && nr[0] == '1');
 	const char *nf = getenv("BLZ_NO_FUSE");
@@ -254,10 +258,43 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
 	HIPCHK(hipMalloc(&D.row_ptr, (size_t)(H.rows + 1) * sizeof(u32)));
 	HIPCHK(hipMemcpy(D.row_ptr, H.row_ptr, (size_t)(H.rows + 1) * sizeof(u32), hipMemcpyHostToDevice));
 	HIPCHK(hipMalloc(&D.col_idx, (size_t)(H.nnz ? H.nnz : 1) * sizeof(int)));
-	HIPCHK(hipMemcpy(D.col_idx, H.col_idx, (size_t)H.nnz * sizeof(int), hipMemcpyHostToDevice));
-	if (H.val) {
-		HIPCHK(hipMalloc(&D.val, (size_t)(H.nnz ? H.nnz : 1) * sizeof(u32)));
-		HIPCHK(hipMemcpy(D.val, H.val, (size_t)H.nnz * sizeof(u32), hipMemcpyHostToDevice));
+	/* Packed stream: when the slab has at most 256 distinct values and fewer than 2^24 columns, each entry
+	 * travels as ONE u32 (column | palette index << 24) instead of two; the SpMV is bound by the number of
+	 * fabric requests, and this halves those of the matrix stream.  BLZ_NO_PACK=1 keeps the plain arrays. */
+	bool packed = false;
+	if (H.val && c->pack && H.cols < (1 << 24)) {
+		std::vector<u32> pal;
+		std::vector<u32> pk((size_t)H.nnz);
+		std::vector<int> slot(4096, -1);	/* open-addressing hash: value -> palette index */
+		packed = true;
+		for (int64_t k = 0; k < H.nnz && packed; k++) {
+			const u32 v = H.val[k];
+			u32 h = (v * 2654435761u) >> 20;
+			while (slot[h] >= 0 && pal[(size_t)slot[h]] != v)
+				h = (h + 1) & 4095u;
+			if (slot[h] < 0) {
+				if (pal.size() == 256) {
+					packed = false;
+					break;
+				}
+				slot[h] = (int)pal.size();
+				pal.push_back(v);
+			}
+			pk[(size_t)k] = (u32)H.col_idx[k] | ((u32)slot[h] << 24);
+		}
+		if (packed) {
+			pal.resize(256, 0);
+			HIPCHK(hipMalloc(&D.palette, 256 * sizeof(u32)));
+			HIPCHK(hipMemcpy(D.palette, pal.data(), 256 * sizeof(u32), hipMemcpyHostToDevice));
+			HIPCHK(hipMemcpy(D.col_idx, pk.data(), (size_t)H.nnz * sizeof(u32), hipMemcpyHostToDevice));
+		}
+	}
+	if (!packed) {
+		HIPCHK(hipMemcpy(D.col_idx, H.col_idx, (size_t)H.nnz * sizeof(int), hipMemcpyHostToDevice));
+		if (H.val) {
+			HIPCHK(hipMalloc(&D.val, (size_t)(H.nnz ? H.nnz : 1) * sizeof(u32)));
+			HIPCHK(hipMemcpy(D.val, H.val, (size_t)H.nnz * sizeof(u32), hipMemcpyHostToDevice));
+		}
 	}
 	(void)c;
 	return BLZ_OK;

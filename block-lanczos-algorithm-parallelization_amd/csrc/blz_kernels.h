@@ -10,7 +10,8 @@ struct DevCsr {
 	int64_t rows = 0, cols = 0, nnz = 0;
 	u32 *row_ptr = nullptr;
 	int *col_idx = nullptr;
-	u32 *val = nullptr;	/* nullptr: all ones */
+	u32 *val = nullptr;	/* nullptr: all ones, or packed (palette != nullptr) */
+	u32 *palette = nullptr;	/* 256 values: col_idx then holds  column | (palette index << 24)  */
 };
 
 /* Control words shared by all kernels of a context (device memory). */

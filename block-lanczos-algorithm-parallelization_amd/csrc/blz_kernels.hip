@@ -38,9 +38,24 @@ MODP_DEV u64 shfl_xor64(u64 x, int mask)
 /* acc += sum over entries [k, e) of val * X[col, xl]; `stride` = words per block row */
 template <typename W>
 MODP_DEV void spmv_accumulate(Acc &acc, u32 k, u32 e, const int *__restrict__ ci, const u32 *__restrict__ va,
-			      const W *__restrict__ X, int stride, int xl)
+			      const u32 *spal, const W *__restrict__ X, int stride, int xl)
 {
-	if (va) {
+	if (spal) {
+		/* packed stream: one u32 per entry = column (24 bits) | index into the value palette (8 bits, in LDS) */
+		for (; k + 4 <= e; k += 4) {
+			const u32 p0 = (u32)ci[k], p1 = (u32)ci[k + 1], p2 = (u32)ci[k + 2], p3 = (u32)ci[k + 3];
+			const W x0 = X[(size_t)(p0 & 0xFFFFFFu) * stride + xl], x1 = X[(size_t)(p1 & 0xFFFFFFu) * stride + xl];
+			const W x2 = X[(size_t)(p2 & 0xFFFFFFu) * stride + xl], x3 = X[(size_t)(p3 & 0xFFFFFFu) * stride + xl];
+			acc_mac32(acc, spal[p0 >> 24], x0);
+			acc_mac32(acc, spal[p1 >> 24], x1);
+			acc_mac32(acc, spal[p2 >> 24], x2);
+			acc_mac32(acc, spal[p3 >> 24], x3);
+		}
+		for (; k < e; k++) {
+			const u32 pk = (u32)ci[k];
+			acc_mac32(acc, spal[pk >> 24], X[(size_t)(pk & 0xFFFFFFu) * stride + xl]);
+		}
+	} else if (va) {
 		for (; k + 4 <= e; k += 4) {
 			const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
 			const u32 a0 = va[k], a1 = va[k + 1], a2 = va[k + 2], a3 = va[k + 3];
@@ -105,7 +120,8 @@ MODP_DEV bool heavy_defer(HeavyList &hl, long long r, int lane, u32 part, int le
 /* all threads of the block: sum row r over BLOCK/G slices; group 0 returns the 128-bit total */
 template <typename W, int G>
 MODP_DEV Acc heavy_row_sum(long long r, const u32 *__restrict__ rp, const int *__restrict__ ci,
-			   const u32 *__restrict__ va, const W *__restrict__ X, int stride, int xl, Acc (*slices)[G])
+			   const u32 *__restrict__ va, const u32 *spal, const W *__restrict__ X, int stride, int xl,
+			   Acc (*slices)[G])
 {
 	constexpr int GPB = BLOCK / G;
 	const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
@@ -114,7 +130,7 @@ MODP_DEV Acc heavy_row_sum(long long r, const u32 *__restrict__ rp, const int *_
 	const u32 lo = k0 + (u32)grp * per;
 	Acc acc;
 	acc_zero(acc);
-	spmv_accumulate<W>(acc, lo < e0 ? lo : e0, (lo + per) < e0 ? (lo + per) : e0, ci, va, X, stride, xl);
+	spmv_accumulate<W>(acc, lo < e0 ? lo : e0, (lo + per) < e0 ? (lo + per) : e0, ci, va, spal, X, stride, xl);
 	slices[grp][lane] = acc;
 	__syncthreads();
 	if (grp == 0)
@@ -127,13 +143,17 @@ MODP_DEV Acc heavy_row_sum(long long r, const u32 *__restrict__ rp, const int *_
 template <typename W, int G, int MERS>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
-       const W *__restrict__ X, W *__restrict__ Y, long long rows, int n, int split_log2, ModP m,
-       const DevCtl *__restrict__ ctl)
+       const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, long long rows, int n, int split_log2,
+       ModP m, const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
 	__shared__ HeavyList hl;
 	__shared__ Acc slices[BLOCK / G][G];
+	__shared__ u32 spal_store[BLOCK];
+	const u32 *spal = pal ? spal_store : nullptr;
+	if (pal)
+		spal_store[threadIdx.x] = pal[threadIdx.x];
 	if (threadIdx.x == 0)
 		hl.cnt = 0;
 	__syncthreads();
@@ -158,7 +178,7 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 		}
 		Acc acc;
 		acc_zero(acc);
-		spmv_accumulate<W>(acc, k, e, ci, va, X, n, xl);
+		spmv_accumulate<W>(acc, k, e, ci, va, spal, X, n, xl);
 		for (int off = G; off < (G << split_log2); off <<= 1)
 			acc_add_acc(acc, shfl_xor64(acc.lo, off), shfl_xor64(acc.hi, off));
 		if (lane < n && part == 0)
@@ -168,7 +188,7 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 	const int nh = hl.cnt < HEAVY_MAX ? hl.cnt : HEAVY_MAX;
 	for (int h = 0; h < nh; h++) {
 		const long long r = hl.rows[h];
-		const Acc acc = heavy_row_sum<W, G>(r, rp, ci, va, X, n, xl, slices);
+		const Acc acc = heavy_row_sum<W, G>(r, rp, ci, va, spal, X, n, xl, slices);
 		if (threadIdx.x < G && lane < n)
 			Y[(size_t)r * n + lane] = (W)acc_reduce<MERS>(acc, m);
 	}
@@ -199,7 +219,7 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 #define SPMV_CASE(GG)                                                                                             \
 	case GG:                                                                                                  \
 		hipLaunchKernelGGL((k_spmv<W, GG, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr,  \
-				   A.col_idx, A.val, X, Y, (long long)A.rows, c.n, split_log2, c.m, ctl);       \
+				   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, c.m, ctl); \
 		break;
 	switch (G) {
 		SPMV_CASE(1)
@@ -416,8 +436,8 @@ k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long ro
 template <typename W, int MERS, int NT>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
-	   const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd, long long rows, ModP m,
-	   u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
+	   const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
+	   long long rows, ModP m, u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
@@ -425,6 +445,10 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
 	__shared__ HeavyList hl;
 	__shared__ Acc slices[BLOCK / NT][NT];
+	__shared__ u32 spal_store[BLOCK];
+	const u32 *spal = pal ? spal_store : nullptr;
+	if (pal)
+		spal_store[threadIdx.x] = pal[threadIdx.x];
 	if (threadIdx.x == 0)
 		hl.cnt = 0;
 	__syncthreads();
@@ -440,7 +464,7 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 		const u64 vi = Vd[(size_t)r * NT + lane];
 		Acc acc;
 		acc_zero(acc);
-		spmv_accumulate<W>(acc, k, e, ci, va, X, NT, lane);
+		spmv_accumulate<W>(acc, k, e, ci, va, spal, X, NT, lane);
 		const u64 y = acc_reduce<MERS>(acc, m);
 		Y[(size_t)r * NT + lane] = (W)y;
 		ds.row(vi, y, lane, gbase, m);
@@ -449,7 +473,7 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 	const int nh = hl.cnt < HEAVY_MAX ? hl.cnt : HEAVY_MAX;
 	for (int h = 0; h < nh; h++) {
 		const long long r = hl.rows[h];
-		const Acc acc = heavy_row_sum<W, NT>(r, rp, ci, va, X, NT, lane, slices);
+		const Acc acc = heavy_row_sum<W, NT>(r, rp, ci, va, spal, X, NT, lane, slices);
 		if (t < NT) {
 			const u64 y = acc_reduce<MERS>(acc, m);
 			Y[(size_t)r * NT + lane] = (W)y;
@@ -473,7 +497,7 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 #define SPMV_DOT(NN)                                                                                                \
 	case NN:                                                                                                    \
 		hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
-				   A.val, X, Y, Vd, (long long)A.rows, c.m, partial, ctl);                           \
+				   A.val, A.palette, X, Y, Vd, (long long)A.rows, c.m, partial, ctl);               \
 		break;
 	switch (c.n) {
 		SPMV_DOT(1)

@@ -247,3 +247,19 @@ def test_results_do_not_depend_on_the_internal_renumbering(monkeypatch, name, p,
             assert np.array_equal(ctx.get_block(blz.TMP), x)
             ctx.spmv(right, blz.TMP, blz.AV)
             assert np.array_equal(ctx.get_block(blz.AV), orc.spmv(Mo, x, right, n, p))
+
+
+@pytest.mark.parametrize("distinct", [5, 256, 300])
+def test_packed_and_plain_matrix_streams_agree(monkeypatch, distinct):
+    """Slabs with <= 256 distinct values and < 2^24 columns travel as one u32 per entry (column | palette index);
+    more values fall back to the two-array form; BLZ_NO_PACK=1 forces it.  Same words either way."""
+    p, n = P61, 8
+    rng = np.random.default_rng(5)
+    nr, nc, nz = 4000, 3500, 40000
+    vals = rng.integers(1, 2 ** 32, size=distinct, dtype=np.uint64)
+    M = blz.Matrix(nr, nc, rng.integers(0, nr, nz), rng.integers(0, nc, nz), vals[rng.integers(0, distinct, nz)].astype(np.uint32))
+    want = orc.block_lanczos(as_orc(M), n, p, stop_after=4)
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BLZ_NO_PACK", flag)
+        got = blz.solve(M, p, n, stop_after=4, batch=4)
+        assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
