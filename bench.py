@@ -175,7 +175,7 @@ def main():
                 # 64 bytes, so the wide coalesced part of this kernel (col_idx, val, row_ptr) is counted at half and
                 # is added back; the 64-byte row gathers are counted at face value (FETCH_SIZE = nnz*64 B + stream/2
                 # to within 0.3 % on this kernel).
-                stream = nnz1 * (4 + (0 if pattern else 4)) + 4 * (loc_t + 1)
+                stream = ctx.matrix_stream_bytes(not right)      # as resident: row_ptr + packed (or plain) entries
                 traffic = rec["FETCH_SIZE_bytes_per_launch"] + stream / 2 + rec["WRITE_SIZE_bytes_per_launch"]
                 traffic_src = os.path.relpath(tpath, ROOT)
 

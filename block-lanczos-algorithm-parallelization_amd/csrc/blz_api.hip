@@ -399,6 +399,14 @@ extern "C" int64_t blz_local_nnz(const blz_ctx *c, int transpose)
 	return (c && c->have_matrix) ? c->csr[transpose ? 1 : 0].nnz : -1;
 }
 
+extern "C" int64_t blz_matrix_stream_bytes(const blz_ctx *c, int transpose)
+{
+	if (!c || !c->have_matrix)
+		return -1;
+	const DevCsr &A = c->csr[transpose ? 1 : 0];
+	return (A.rows + 1) * 4 + A.nnz * 4 + (A.val ? A.nnz * 4 : 0);
+}
+
 /* host u64 words -> device words of the context's width */
 static int put_words(blz_ctx *c, void *dst, const uint64_t *src, int64_t words)
 {

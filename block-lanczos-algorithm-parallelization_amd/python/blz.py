@@ -51,6 +51,7 @@ def lib():
         L.blz_local_rows.restype = C.c_int64
         L.blz_iterations.restype = C.c_int64
         L.blz_local_nnz.restype = C.c_int64
+        L.blz_matrix_stream_bytes.restype = C.c_int64
         L.blz_destroy.restype = None
         L.blz_coo_free.restype = None
         L.blz_csr_free.restype = None
@@ -236,6 +237,9 @@ class Context:
 
     def local_nnz(self, transpose):
         return int(lib().blz_local_nnz(self.h, C.c_int(int(transpose))))
+
+    def matrix_stream_bytes(self, transpose):
+        return int(lib().blz_matrix_stream_bytes(self.h, C.c_int(int(transpose))))
 
     def owner_of_row(self, block, row):
         return int(lib().blz_owner_of_row(self.h, C.c_int(block), C.c_int64(row)))

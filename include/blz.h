@@ -169,6 +169,8 @@ int blz_owner_of_row(const blz_ctx *ctx, int block, int64_t row);
 int64_t blz_rows(const blz_ctx *ctx, int block);	/* global row count of a block (N or C) */
 int64_t blz_local_rows(const blz_ctx *ctx, int block, int64_t *first);	/* this rank's slab */
 int64_t blz_local_nnz(const blz_ctx *ctx, int transpose);		/* entries of this rank's slab of M (0) or M^T (1) */
+int64_t blz_matrix_stream_bytes(const blz_ctx *ctx, int transpose);	/* bytes of that slab as resident in HBM
+									 * (row_ptr + packed or plain col_idx/val) */
 
 /* v <- random64() % p for this rank's rows, everything else 0 (:617-625). */
 int blz_init_v(blz_ctx *ctx);
