@@ -263,3 +263,23 @@ def test_packed_and_plain_matrix_streams_agree(monkeypatch, distinct):
         monkeypatch.setenv("BLZ_NO_PACK", flag)
         got = blz.solve(M, p, n, stop_after=4, batch=4)
         assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
+
+
+def test_abi_misuse_is_reported_not_crashed():
+    with blz.Context(P61, 4) as ctx:
+        for call in (lambda: ctx.init_v(), lambda: ctx.iterate(1), lambda: ctx.spmv(False, blz.V, blz.TMP),
+                     lambda: ctx.set_block(blz.V, np.zeros(4, np.uint64)) if False else ctx.orthogonalize(),
+                     lambda: ctx.final_check()):
+            with pytest.raises(blz.BlzError) as e:
+                call()
+            assert e.value.code == blz.EINVAL and "no matrix" in str(e.value)
+        M = blz.Matrix.load(os.path.join(GOLDEN, "quirks40x30.mtx"), P61)
+        ctx.set_matrix(M, False)
+        with pytest.raises(blz.BlzError):
+            ctx.spmv(False, blz.V, blz.V)                # src == dst
+        with pytest.raises(blz.BlzError):
+            blz.check(blz.lib().blz_set_small(ctx.h, 9, blz.ptr(np.zeros(16, np.uint64))))
+        with pytest.raises(blz.BlzError):
+            ctx.set_matrix(M, False, 2, 2)               # rank out of range
+        ctx.set_matrix(M, True)                          # re-loading another orientation is fine
+        assert ctx.rows(blz.V) == 30 and ctx.rows(blz.TMP) == 40
