@@ -815,12 +815,172 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, 
 	}
 }
 
+/*
+ * Register-resident form for n*n <= 64 (n <= 8): lane (i,k) = (lane >> LG, lane & (G-1)) of the single wavefront
+ * holds A[i][k], W[i][k] and the scalar of row i; pivot search is one ballot, row swaps / broadcasts are cross-lane
+ * reads.  No LDS round trips: the serial chain per column is three shuffles and two MACs.  Same fraction-free
+ * sweep, same pivot rule, same single inversion as k_semi_inverse.
+ */
+template <int MERS, int LG>
+__device__ static int ff_sweep_reg(u64 &a, u64 *w, u64 *s, int n, const ModP &m, u64 *mask)
+{
+	constexpr int G = 1 << LG;
+	const int lane = threadIdx.x, i = lane >> LG, k = lane & (G - 1);
+	const bool valid = i < n && k < n;
+	int found = 0;
+	u64 bits = 0;
+	for (int j = 0; j < n; j++) {
+		const unsigned long long cand = __ballot(valid && k == j && i >= j && a != 0);
+		if (cand == 0)
+			continue;
+		const int piv = (__ffsll(cand) - 1) >> LG;
+		bits |= 1ull << j;
+		found++;
+		const int from = ((i == j ? piv : (i == piv ? j : i)) << LG) + k;	/* swap rows piv <-> j */
+		a = shfl64(a, from);
+		if (w)
+			*w = shfl64(*w, from);
+		if (s)
+			*s = shfl64(*s, from);
+		const u64 pv = shfl64(a, (j << LG) + j);
+		if (s && i == j)
+			*s = pv;
+		const u64 mult = shfl64(a, (i << LG) + j), y = shfl64(a, (j << LG) + k);
+		const u64 wy = w ? shfl64(*w, (j << LG) + k) : 0;
+		if (valid && i != j && mult != 0) {
+			const u64 neg = m.p - mult;
+			Acc acc;
+			acc_zero(acc);
+			acc_mac64(acc, pv, a);
+			acc_set(acc, acc_reduce<MERS>(acc, m));
+			acc_mac64(acc, neg, y);
+			a = acc_reduce<MERS>(acc, m);
+			if (w) {
+				acc_zero(acc);
+				acc_mac64(acc, pv, *w);
+				acc_set(acc, acc_reduce<MERS>(acc, m));
+				acc_mac64(acc, neg, wy);
+				*w = acc_reduce<MERS>(acc, m);
+			}
+			if (s)
+				*s = mulmod<MERS>(*s, pv, m);
+		}
+	}
+	*mask = bits;
+	return found;
+}
+
+template <int MERS, int LG>
+__global__ void __launch_bounds__(64)
+k_semi_inverse_reg(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, ModP m, int in_loop)
+{
+	if (in_loop && ctl->stop)
+		return;
+	constexpr int G = 1 << LG;
+	const int nn = n * n, lane = threadIdx.x, i = lane >> LG, k = lane & (G - 1);
+	const bool valid = i < n && k < n;
+	const int e = valid ? i * n + k : 0;
+	u64 *vtAv = small, *vtAAv = small + nn, *winv = small + 2 * nn, *dvec = small + 3 * nn;
+	u64 *cmat = small + 4 * nn, *vtAvd = small + 5 * nn;
+	/* inputs may be sums of per-rank residues: bring them back into [0,p) */
+	const u64 x0 = valid ? reduce128<MERS>(0, vtAv[e], m) : 0, y0 = valid ? reduce128<MERS>(0, vtAAv[e], m) : 0;
+	if (valid) {
+		vtAv[e] = x0;
+		vtAAv[e] = y0;
+	}
+	u64 sel = 0, dbits = 0;
+	u64 a = x0;
+	ff_sweep_reg<MERS, LG>(a, nullptr, nullptr, n, m, &sel);			/* phase 1, :349-382 */
+	const bool both = valid && ((sel >> i) & 1) && ((sel >> k) & 1);
+	a = both ? x0 : 0;								/* :384-388 */
+	u64 w = (valid && i == k && ((sel >> i) & 1)) ? 1 : 0, s = 1;
+	const int npiv = ff_sweep_reg<MERS, LG>(a, &w, &s, n, m, &dbits);		/* phase 2, :389-436 */
+	/* one inversion for all row scalars: prefix products, then walk back (uniform over the wavefront) */
+	u64 pre[G], run = 1;
+#pragma unroll
+	for (int r = 0; r < G; r++) {
+		const u64 sr = shfl64(s, r << LG);
+		if (r < n)
+			run = mulmod<MERS>(run, sr, m);
+		pre[r] = run;
+	}
+	u64 inv = dev_invmod(run, m.p), mine = 0;
+#pragma unroll
+	for (int r = G - 1; r >= 0; r--) {
+		const u64 sr = shfl64(s, r << LG);
+		if (r < n) {
+			const u64 ir = r ? mulmod<MERS>(inv, pre[r - 1], m) : inv;
+			if (r == i)
+				mine = ir;
+			inv = mulmod<MERS>(inv, sr, m);
+		}
+	}
+	const u64 wn = valid ? mulmod<MERS>(w, mine, m) : 0;
+	if (valid)
+		winv[e] = wn;
+	if (lane < n)
+		dvec[lane] = (dbits >> lane) & 1;
+	/* c = -(winv * spliced), vtAvd = -vtAv on the selected columns (:462-475), canonical; lane (i,k) owns c[i][k] */
+	const bool dk = (dbits >> k) & 1;
+	const u64 sp = dk ? y0 : x0;						/* spliced[i][k] */
+	Acc acc;
+	acc_zero(acc);
+	u32 cnt = 0;
+#pragma unroll
+	for (int q = 0; q < G; q++) {
+		const u64 wiq = shfl64(wn, (i << LG) + q), sqk = shfl64(sp, (q << LG) + k);
+		if (q < n) {
+			acc_mac64(acc, wiq, sqk);
+			if (++cnt == m.chunk) {
+				cnt = 0;
+				acc_set(acc, acc_reduce<MERS>(acc, m));
+			}
+		}
+	}
+	if (valid) {
+		const u64 r = acc_reduce<MERS>(acc, m);
+		cmat[e] = r ? m.p - r : 0;
+		vtAvd[e] = (dk && x0) ? m.p - x0 : 0;
+	}
+	if (lane == 0) {
+		ctl->npiv = npiv;
+		if (in_loop) {
+			if (npiv == 0)
+				ctl->stop = 1;
+			else
+				ctl->iterations += 1;
+		}
+	}
+}
+
 hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int in_loop, hipStream_t s)
 {
-	const size_t lds = ((size_t)2 * c.n * c.n + 2 * c.n) * sizeof(u64);
-	int G = 1;
-	while (G < c.n)
+	int G = 1, LG = 0;
+	while (G < c.n) {
 		G <<= 1;
+		LG++;
+	}
+	if (c.n <= 8) {		/* the whole n x n problem fits one wavefront's registers */
+#define SEMI_REG(MM, LL)                                                                                          \
+	hipLaunchKernelGGL((k_semi_inverse_reg<MM, LL>), dim3(1), dim3(64), 0, s, small, ctl, c.n, c.m, in_loop)
+#define SEMI_REG_LG(MM)                                                                                           \
+	do {                                                                                                      \
+		if (LG == 0) SEMI_REG(MM, 0);                                                                     \
+		else if (LG == 1) SEMI_REG(MM, 1);                                                                \
+		else if (LG == 2) SEMI_REG(MM, 2);                                                                \
+		else SEMI_REG(MM, 3);                                                                             \
+	} while (0)
+		if (c.mers == 61)
+			SEMI_REG_LG(61);
+		else if (c.mers == 31)
+			SEMI_REG_LG(31);
+		else
+			SEMI_REG_LG(0);
+#undef SEMI_REG_LG
+#undef SEMI_REG
+		return hipGetLastError();
+	}
+	const size_t lds = ((size_t)2 * c.n * c.n + 2 * c.n) * sizeof(u64);
 #define SEMI(MM)                                                                                                   \
 	do {                                                                                                       \
 		if (lds > 48 * 1024)                                                                               \
