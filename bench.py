@@ -40,6 +40,9 @@ WORKLOADS = {
     # all-ones pattern path, n=16, 128-byte block rows)
     "synth5q": dict(desc="config-5-shape synthetic at 1/4 linear scale (all-ones pattern)", rows=12500000, cols=12500000,
                     nnz=500000000, prime=P61, n=16, right=False, seed=0x53594E35, pattern=True),
+    # config 5 at FULL size on one GPU (fits: ~42 GB of the 288 GB HBM); minutes of host-side set-up
+    "synth5": dict(desc="config-5 synthetic (all-ones pattern), full size on ONE GPU", rows=50000000, cols=50000000,
+                   nnz=2000000000, prime=P61, n=16, right=False, seed=0x53594E35, pattern=True),
     "tiny": dict(desc="tiny synthetic (self-test)", rows=20000, cols=15000, nnz=200000, prime=P61,
                  n=8, right=False, seed=0x54494E59, pattern=False),
 }

@@ -20,6 +20,15 @@ MODP_DEV u64 shfl64(u64 x, int src)
 	return ((u64)hi << 32) | lo;
 }
 
+/* the same with the byte address of the source lane (lane * 4) precomputed by the caller: one ds_bpermute per half,
+ * no per-call index arithmetic */
+MODP_DEV u64 bperm64(u64 x, int src_lane_x4)
+{
+	const u32 lo = (u32)__builtin_amdgcn_ds_bpermute(src_lane_x4, (int)(u32)x);
+	const u32 hi = (u32)__builtin_amdgcn_ds_bpermute(src_lane_x4, (int)(u32)(x >> 32));
+	return ((u64)hi << 32) | lo;
+}
+
 MODP_DEV u64 shfl_xor64(u64 x, int mask)
 {
 	const u32 lo = (u32)__shfl_xor((int)(u32)x, mask, 64), hi = (u32)__shfl_xor((int)(u32)(x >> 32), mask, 64);
@@ -357,7 +366,7 @@ struct DotState {
 	{
 #pragma unroll
 		for (int q = 0; q < NT; q++) {
-			const u64 aq = q == 0 ? ai : shfl64(ai, gbase + ((i + q) & (NT - 1)));
+			const u64 aq = q == 0 ? ai : bperm64(ai, (gbase + ((i + q) & (NT - 1))) * 4);
 			acc_mac64(a1[q], vi, aq);
 			if (q < H)
 				acc_mac64(a2[q], ai, aq);
@@ -1093,6 +1102,7 @@ k_orthogonalize_fast(W *__restrict__ V, const W *__restrict__ AV, W *__restrict_
 	}
 	const bool dj = small[3 * NN + j] != 0;
 	const long long g0 = (long long)blockIdx.x * GPB + t / NT, ng = (long long)gridDim.x * GPB;
+	const int src0 = gbase * 4;			/* byte address of lane 0 of the group for ds_bpermute */
 	for (long long r = g0; r < rows; r += ng) {
 		const size_t at = (size_t)r * NT + j;
 		const u64 vv = V[at], aa = AV[at], pp = P[at];
@@ -1101,7 +1111,7 @@ k_orthogonalize_fast(W *__restrict__ V, const W *__restrict__ AV, W *__restrict_
 		acc_set(ap, dj ? 0 : pp);
 #pragma unroll
 		for (int k = 0; k < NT; k++) {
-			const u64 vk = NT == 1 ? vv : shfl64(vv, gbase + k), pk = NT == 1 ? pp : shfl64(pp, gbase + k);
+			const u64 vk = NT == 1 ? vv : bperm64(vv, src0 + 4 * k), pk = NT == 1 ? pp : bperm64(pp, src0 + 4 * k);
 			acc_mac64(av, vk, cc[k]);
 			acc_mac64(av, pk, vd[k]);
 			acc_mac64(ap, vk, ww[k]);
@@ -1122,6 +1132,11 @@ static hipError_t ortho_dispatch(const KernelCfg &c, W *V, const W *AV, W *P, in
 	if ((n == 1 || n == 2 || n == 4 || n == 8 || n == 16) && c.m.chunk >= 2u * (unsigned)n) {
 		const long long gpb = BLOCK / n;
 		long long blocks = (rows + gpb - 1) / gpb;
+		/* persistent grid = what is resident at once (registers allow 5 / 3 blocks of 256 per CU at n = 8 / 16):
+		 * a grid of 8 per CU would run as 1.6 "rounds" and end on a half-empty chip */
+		const long long fit = (long long)c.num_cu * (n >= 16 ? 3 : (n >= 8 ? 5 : 8));
+		if (blocks > fit)
+			blocks = fit;
 		if (blocks > cap)
 			blocks = cap;
 #define ORTHO_FAST(NN)                                                                                               \

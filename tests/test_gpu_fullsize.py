@@ -84,3 +84,17 @@ def test_full_size_config(name):
         BU = ctx.get_block(blz.TMP)
         rhs, _ = orc.block_dot(nt, Wb, BU, n, p, omp_threads=threads)   # (B U)^T W, summed on the host
         assert np.array_equal(lhs, rhs)
+
+
+def test_full_solve_finds_verified_kernel_vectors():
+    """A whole solve at moderate scale (24 k iterations): 200 000 x 190 000, 2 M entries, n=8, p=2^61-1.  More rows than
+    columns, so a left kernel exists; the block returned must be non-zero and annihilate M -- checked on the host
+    with the oracle's SpMV, i.e. independently of every GPU kernel."""
+    p, n = (1 << 61) - 1, 8
+    M = blz.Matrix.synth(200000, 190000, 2000000, 0x534F4C56, p)
+    res = blz.solve(M, p, n, batch=512)
+    assert res["final_check"] == (True, True)
+    assert 190000 // n - 50 <= res["iterations"] <= 190000 // n + 1
+    Mo = orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+    assert res["v"].any()
+    assert not orc.spmv_omp(Mo, res["v"], True, n, p, min(16, os.cpu_count() or 1)).any()
