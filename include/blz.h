@@ -167,7 +167,8 @@ int blz_set_matrix(blz_ctx *ctx, const blz_coo *M, int right, int rank, int nran
 int blz_owner_of_row(const blz_ctx *ctx, int block, int64_t row);
 
 int64_t blz_rows(const blz_ctx *ctx, int block);	/* global row count of a block (N or C) */
-int64_t blz_local_rows(const blz_ctx *ctx, int block, int64_t *first);	/* this rank's slab */
+/* size of this rank's slab of a block; *first = its first row in the SOLVER's numbering (see blz_owner_of_row) */
+int64_t blz_local_rows(const blz_ctx *ctx, int block, int64_t *first);
 int64_t blz_local_nnz(const blz_ctx *ctx, int transpose);		/* entries of this rank's slab of M (0) or M^T (1) */
 int64_t blz_matrix_stream_bytes(const blz_ctx *ctx, int transpose);	/* bytes of that slab as resident in HBM
 									 * (row_ptr + packed or plain col_idx/val) */
@@ -211,8 +212,9 @@ int blz_set_iterations(blz_ctx *ctx, int64_t iterations);	/* --load-checkpoint *
 int blz_final_check(blz_ctx *ctx, int *v_nonzero, int *vtm_zero);
 
 /* Measurement: run one hot-path kernel `reps` times between two HIP events on the context's
- * stream and return the mean time.  which: 0 = first SpMV of an iteration (:635), 1 = second
- * (:636), 2 = block_dot, 3 = orthogonalize (on scratch copies), 4 = whole iteration. */
+ * stream and return the mean time.  which: 0 = first SpMV of an iteration (:635), 1 = second (:636, without
+ * the fused block products), 2 = block_dot + finalize, 3 = orthogonalize (updates V and P in place: call
+ * blz_init_v or blz_set_block afterwards if the blocks are to be used again). */
 int blz_time_kernel(blz_ctx *ctx, int which, int reps, float *ms_mean);
 int blz_sync(blz_ctx *ctx);
 
