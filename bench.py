@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--workload", default="gl7d19", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--ref-iterations", type=int, default=40,
+                    help="iterations of the unmodified reference OpenMP binary on a 1/16-scale sample (0 = skip)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): RCCL and gloo print banners to fd 1 from native code, so fd 1 is
@@ -259,6 +261,42 @@ def main():
         out["cpu_baseline"]["gpu_equals_cpu_after_sample"] = same
         if not same:
             sys.exit("bench.py: GPU and CPU baseline disagree after the sampled iterations")
+
+    # ---- the reference's own OpenMP program (oracle/_ref, compiled from its sources) on this box's host cores.
+    # It cannot run the benchmark's configuration (p is capped at 2^30-35, u32 words, its u64 sums overflow on large
+    # values, and it only reads files), so it gets a 1/16-scale all-ones sample of the same shape and density with
+    # the largest prime it accepts.  Reported next to cpu_baseline, which is the same-workload port.
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "lanczos_modp_omp_ref")
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.ref_iterations > 0 and os.path.exists(ref_exe):
+        import re
+        import subprocess
+        import tempfile
+        p_ref, scale = 1073741789, 16
+        S = blz.Matrix.synth(max(w["rows"] // scale, 64), max(w["cols"] // scale, 64), max(w["nnz"] // scale, 64), w["seed"], p_ref,
+                             pattern=True)
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "sample.mtx")
+            S.save(path)
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_STACKSIZE="1G")
+            cmd = [ref_exe, "--matrix", path, "--prime", str(p_ref), "--n", str(n), "--stop-after", str(args.ref_iterations)]
+            if right:
+                cmd.append("--right")
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=td, timeout=240)
+                mt = re.search(r"Terminated in ([0-9.]+)s after (\d+) iterations", r.stdout)
+                if r.returncode == 0 and mt and float(mt.group(1)) > 0:
+                    t_ref, k_ref = float(mt.group(1)), int(mt.group(2))
+                    out["cpu_reference"] = {
+                        "value": 2 * S.nnz * n * k_ref / t_ref, "unit": "MAC/s", "cores": threads, "kind": "reference",
+                        "sample": f"openMP/lanczos_modp.c (unmodified, oracle/_ref) --stop-after {k_ref} on a 1/{scale}-scale all-ones "
+                                  f"sample of the same shape ({S.nrows}x{S.ncols}, {S.nnz} nnz), --prime {p_ref} --n {n}: "
+                                  f"{t_ref:.1f} s main loop",
+                        "s_per_iteration": t_ref / max(k_ref, 1)}
+                else:
+                    out["cpu_reference"] = {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as exc:   # the reference is a reported extra, never a reason to lose the bench line
+                out["cpu_reference"] = {"error": repr(exc)}
 
     ctx.close()
     if rank == 0:

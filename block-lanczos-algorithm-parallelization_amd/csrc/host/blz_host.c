@@ -187,6 +187,24 @@ int blz_mm_load(const char *path, uint64_t prime, blz_coo *out)
 	return BLZ_OK;
 }
 
+int blz_mm_save_coo(const char *path, const blz_coo *M)
+{
+	if (!path || !M)
+		return blz_fail(BLZ_EINVAL, "blz_mm_save_coo: bad argument");
+	FILE *f = fopen(path, "w");
+	if (!f)
+		return blz_fail(BLZ_EIO, "cannot open %s: %s", path, strerror(errno));
+	static char iobuf[1 << 20];
+	setvbuf(f, iobuf, _IOFBF, sizeof iobuf);
+	fprintf(f, "%%%%MatrixMarket matrix coordinate integer general\n%ld %ld %ld\n", (long)M->nrows, (long)M->ncols,
+		(long)M->nnz);
+	for (int64_t k = 0; k < M->nnz; k++)
+		fprintf(f, "%d %d %u\n", M->i[k] + 1, M->j[k] + 1, M->x[k]);
+	if (fclose(f))
+		return blz_fail(BLZ_EIO, "write error on %s", path);
+	return BLZ_OK;
+}
+
 void blz_coo_free(blz_coo *M)
 {
 	if (!M)

@@ -110,6 +110,9 @@ class Matrix:
                                   C.c_int(int(pattern)), C.c_uint64(prime), C.byref(M)))
         return Matrix._take(M)
 
+    def save(self, path):
+        check(lib().blz_mm_save_coo(path.encode(), C.byref(self.c)))
+
     def csr(self, transpose=False, pattern=True):
         A = Csr()
         check(lib().blz_csr_from_coo(C.byref(self.c), C.c_int(int(transpose)), C.c_int(int(pattern)), C.byref(A)))

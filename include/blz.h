@@ -75,6 +75,10 @@ typedef struct {
 int blz_mm_load(const char *path, uint64_t prime, blz_coo *out);
 void blz_coo_free(blz_coo *M);
 
+/* Write triplets as a MatrixMarket "coordinate integer general" file (1-based, values as stored).  Used to hand a
+ * synthetic matrix to programs that only read files (the reference binaries). */
+int blz_mm_save_coo(const char *path, const blz_coo *M);
+
 /* Seeded synthetic stand-in for a SuiteSparse matrix that is not on the box:
  * row r gets floor(nnz/R) + (r < nnz mod R) distinct uniform columns; values from
  * {1,1,1,2,3,-1,-2} (pattern=0, canonicalised like the loader does) or all 1 (pattern=1). */
