@@ -66,8 +66,8 @@ def main():
     ap.add_argument("--workload", default="gl7d19", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--ref-iterations", type=int, default=40,
-                    help="iterations of the unmodified reference OpenMP binary on a 1/16-scale sample (0 = skip)")
+    ap.add_argument("--ref-iterations", type=int, default=100,
+                    help="iterations of the unmodified reference OpenMP binary on a 1/4-scale sample (0 = skip)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): RCCL and gloo print banners to fd 1 from native code, so fd 1 is
@@ -264,14 +264,14 @@ def main():
 
     # ---- the reference's own OpenMP program (oracle/_ref, compiled from its sources) on this box's host cores.
     # It cannot run the benchmark's configuration (p is capped at 2^30-35, u32 words, its u64 sums overflow on large
-    # values, and it only reads files), so it gets a 1/16-scale all-ones sample of the same shape and density with
+    # values, and it only reads files), so it gets a 1/4-scale all-ones sample of the same shape and density with
     # the largest prime it accepts.  Reported next to cpu_baseline, which is the same-workload port.
     ref_exe = os.path.join(ROOT, "oracle", "_ref", "lanczos_modp_omp_ref")
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.ref_iterations > 0 and os.path.exists(ref_exe):
         import re
         import subprocess
         import tempfile
-        p_ref, scale = 1073741789, 16
+        p_ref, scale = 1073741789, 4
         S = blz.Matrix.synth(max(w["rows"] // scale, 64), max(w["cols"] // scale, 64), max(w["nnz"] // scale, 64), w["seed"], p_ref,
                              pattern=True)
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
