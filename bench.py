@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--workload", default="gl7d19", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--ref-iterations", type=int, default=100,
+    ap.add_argument("--ref-iterations", type=int, default=50,
                     help="iterations of the unmodified reference OpenMP binary on a 1/4-scale sample (0 = skip)")
     args = ap.parse_args()
 
