@@ -123,3 +123,30 @@ def test_argument_validation_matches_reference():
     assert "2**62" in run(["--help"]).stdout
     bad = run(["--matrix", os.path.join(GOLDEN, "absent.mtx"), "--prime", "65537"])
     assert bad.returncode == 1
+
+
+@pytest.mark.gpu
+def test_config2_end_to_end_is_accepted_by_the_reference_checker(tmp_path):
+    """BASELINE config 2 as a user would run it: relat8-shape matrix in a .mtx file, `lanczos_modp --prime 2^31-1 --n 4
+    --output-file`, then the UNMODIFIED reference checker_modp (oracle/_ref, built from the reference's sources) and
+    the widened checker on the result.  p = 2^31-1 is beyond what the reference solver accepts (cap 2^30-35) but
+    within what its checker can parse."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import blz
+    from bench import WORKLOADS
+    w = WORKLOADS["relat8"]
+    M = blz.Matrix.synth(w["rows"], w["cols"], w["nnz"], w["seed"], w["prime"])
+    mpath, out = str(tmp_path / "relat8_shape.mtx"), str(tmp_path / "kernel.mtx")
+    M.save(mpath)
+    r = run(["--matrix", mpath, "--prime", str(w["prime"]), "--n", str(w["n"]), "--output-file", out])
+    assert r.returncode == 0, r.stderr
+    assert "- OK:    v != 0" in r.stdout and "- OK: vt*M == 0" in r.stdout
+    its = int(r.stdout.split("after")[1].split()[0])
+    assert w["cols"] // w["n"] - 20 <= its <= w["cols"] // w["n"] + 1
+    chk = subprocess.run([CHECKER, "--matrix", mpath, "--kernel", out, "--prime", str(w["prime"])], capture_output=True, text=True)
+    assert chk.returncode == 0 and "OK" in chk.stdout, chk.stderr
+    if os.path.exists(REF_CHECKER):
+        ref = subprocess.run([REF_CHECKER, "--matrix", mpath, "--kernel", out, "--prime", str(w["prime"])],
+                             capture_output=True, text=True, timeout=300)
+        assert ref.returncode == 0 and ref.stdout.rstrip().endswith("OK"), ref.stdout[-300:] + ref.stderr[-300:]
