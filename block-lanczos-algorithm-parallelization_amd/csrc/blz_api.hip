@@ -42,15 +42,18 @@ struct Rccl {
 Rccl g_rccl;
 
 /* RCCL is resolved at run time and only when a communicator is asked for: a single-GPU solve has
- * no dependency on it.  In a process that already loaded an RCCL (e.g. torch's) that copy is used. */
+ * no dependency on it. */
 int rccl_load()
 {
 	if (g_rccl.handle)
 		return BLZ_OK;
-	const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+	/* Prefer the RCCL that belongs to the ROCm installation this library was built against (the HIP runtime the
+	 * process uses is /opt/rocm's when libblz_hip.so is loaded first); BLZ_RCCL_PATH overrides; a copy already
+	 * mapped under the plain soname (e.g. torch's) is the last resort. */
+	const char *names[] = { getenv("BLZ_RCCL_PATH"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so" };
 	void *h = nullptr;
 	for (const char *nm : names)
-		if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)))
+		if (nm && nm[0] && (h = dlopen(nm, RTLD_NOW | RTLD_LOCAL)))
 			break;
 	if (!h)
 		return blz_fail(BLZ_ECOMM, "cannot load librccl: %s", dlerror());
