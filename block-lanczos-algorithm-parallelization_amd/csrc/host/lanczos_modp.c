@@ -28,7 +28,7 @@
 static long n = 1;
 static uint64_t prime;
 static char *matrix_filename, *kernel_filename;
-static bool right_kernel, checkpoints, load_checkpoint;
+static bool right_kernel, checkpoints, load_checkpoint, verify;
 static int stop_after = -1, checkpoint_timer = 60, device, gpus = 1;
 
 static double wtime(void)
@@ -66,6 +66,8 @@ static void usage(char **argv)
 	printf("--stop-after N              stop the algorithm after N iterations\n");
 	printf("--checkpoint [cp]           make a checkpoint every cp seconds [default 60] (lanczos_modp.ckpt)\n");
 	printf("--load-checkpoint           restart from the checkpoint in the current directory\n");
+	printf("--verify                    check the reference's per-iteration invariants (correctness_tests) on the host;\n");
+	printf("                            one host round trip per iteration, for debugging\n");
 	printf("--device D                  first HIP device to run on [default 0]\n");
 	printf("--gpus G                    row-partition the matrix over G GPUs of this node (devices D..D+G-1), RCCL\n");
 	printf("                            all-gather of the block before each product [default 1]\n");
@@ -83,7 +85,8 @@ static void process_command_line_options(int argc, char **argv)
 		{"right", no_argument, NULL, 'r'}, {"left", no_argument, NULL, 'l'},
 		{"stop-after", required_argument, NULL, 's'}, {"checkpoint", optional_argument, NULL, 'c'},
 		{"load-checkpoint", no_argument, NULL, 'L'}, {"device", required_argument, NULL, 'd'},
-		{"gpus", required_argument, NULL, 'g'}, {"help", no_argument, NULL, 'h'}, {NULL, 0, NULL, 0}
+		{"gpus", required_argument, NULL, 'g'}, {"verify", no_argument, NULL, 'V'},
+		{"help", no_argument, NULL, 'h'}, {NULL, 0, NULL, 0}
 	};
 	int ch;
 	while ((ch = getopt_long(argc, argv, "", longopts, NULL)) != -1) {
@@ -105,6 +108,7 @@ static void process_command_line_options(int argc, char **argv)
 		case 'L': load_checkpoint = true; break;
 		case 'd': device = atoi(optarg); break;
 		case 'g': gpus = atoi(optarg); break;
+		case 'V': verify = true; break;
 		case 'h': usage(argv); break;
 		default: errx(1, "Unknown option\n");
 		}
@@ -161,6 +165,35 @@ static void verbosity(void)
 	printf("\r    - iteration %d / %d. %.3fs per iteration. ETA: %s", n_iterations, expected_iterations,
 	       per_iteration, eta);
 	fflush(stdout);
+}
+
+/*
+ * correctness_tests(), sequential/lanczos_modp.c:532-557, on the n x n operands of the iteration just computed:
+ * vtAv, vtAAv, winv symmetric; winv[i][j] != 0 only if d[i] or d[j]; winv * (vtAv restricted to the selected
+ * columns) == diag(d).  The reference asserts these every iteration ("disable in production"); here they are the
+ * --verify mode.
+ */
+static void correctness_tests(blz_ctx *ctx)
+{
+	const int nn = (int)(n * n);
+	uint64_t *A = malloc(sizeof *A * (size_t)(3 * nn + n)), *B = A + nn, *W = B + nn, *d = W + nn;
+	CHECK(blz_get_small(ctx, BLZ_VTAV, A));
+	CHECK(blz_get_small(ctx, BLZ_VTAAV, B));
+	CHECK(blz_get_small(ctx, BLZ_WINV, W));
+	CHECK(blz_get_small(ctx, BLZ_D, d));
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++) {
+			if (A[i * n + j] != A[j * n + i] || B[i * n + j] != B[j * n + i] || W[i * n + j] != W[j * n + i])
+				errx(1, "--verify: iteration %d: an n x n operand is not symmetric at (%d,%d)", n_iterations, i, j);
+			if (W[i * n + j] != 0 && !d[i] && !d[j])
+				errx(1, "--verify: iteration %d: winv[%d][%d] != 0 outside the selected block", n_iterations, i, j);
+			unsigned __int128 acc = 0;
+			for (int k = 0; k < n; k++)
+				acc = (acc + (unsigned __int128)W[i * n + k] * (d[j] ? A[k * n + j] : 0)) % prime;
+			if ((uint64_t)acc != (uint64_t)(i == j ? d[i] : 0))
+				errx(1, "--verify: iteration %d: winv * vtAv * D != D at (%d,%d)", n_iterations, i, j);
+		}
+	free(A);
 }
 
 /*
@@ -306,7 +339,7 @@ int main(int argc, char **argv)
 	double checkpoint_start = wtime();
 	int batch = 1, stopped = 0;
 	while (!stopped) {
-		int todo = batch;
+		int todo = verify ? 1 : batch;
 		if (stop_after > 0) {
 			if (n_iterations >= stop_after)
 				break;
@@ -319,6 +352,8 @@ int main(int argc, char **argv)
 		const float ms = team.ms[0];
 		stopped = team.stopped[0];
 		n_iterations += done;
+		if (verify)
+			correctness_tests(ctx);
 		verbosity();
 		/* keep the host out of the loop: grow the batch until one batch takes ~0.25 s */
 		if (ms < 250.0f && batch < 4096)

@@ -150,3 +150,13 @@ def test_config2_end_to_end_is_accepted_by_the_reference_checker(tmp_path):
         ref = subprocess.run([REF_CHECKER, "--matrix", mpath, "--kernel", out, "--prime", str(w["prime"])],
                              capture_output=True, text=True, timeout=300)
         assert ref.returncode == 0 and ref.stdout.rstrip().endswith("OK"), ref.stdout[-300:] + ref.stderr[-300:]
+
+
+@pytest.mark.gpu
+def test_verify_mode_runs_the_reference_invariants(tmp_path):
+    mpath = os.path.join(GOLDEN, "rand300x200.mtx")
+    out = str(tmp_path / "k.mtx")
+    r = run(["--matrix", mpath, "--prime", "65537", "--n", "4", "--verify", "--output-file", out])
+    assert r.returncode == 0, r.stderr
+    cli = json.load(open(os.path.join(GOLDEN, "cli.json")))
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == cli["rand300x200_p65537_n4_left"]["out_sha256"]
