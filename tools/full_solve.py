@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Whole solve of a bench workload on one GPU, result verified on the host with the oracle's SpMV (test infrastructure).
+Usage: tools/full_solve.py gl7d19 [--right]"""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "block-lanczos-algorithm-parallelization_amd", "python"), os.path.join(ROOT, "oracle"), ROOT]
+import blz, bench, oracle as orc
+name = sys.argv[1]
+w = dict(bench.WORKLOADS[name])
+right = ("--right" in sys.argv) or w["right"]
+p, n = w["prime"], w["n"]
+M = blz.Matrix.synth(w["rows"], w["cols"], w["nnz"], w["seed"], p, pattern=w["pattern"])
+ctx = blz.Context(p, n)
+t0 = time.time()
+ctx.set_matrix(M, right)
+ctx.init_v()
+t_setup = time.time() - t0
+t0 = time.time()
+dev_ms, last = 0.0, t0
+while True:
+    done, stopped, ms = ctx.iterate(2048)
+    dev_ms += ms
+    if time.time() - last > 30:
+        print(f"  iteration {ctx.iterations}  ({dev_ms/1e3:.1f} s of device time)", flush=True)
+        last = time.time()
+    if stopped:
+        break
+wall = time.time() - t0
+nz, zero = ctx.final_check()
+v = ctx.get_block(blz.V)
+Mo = orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+chk = orc.spmv_omp(Mo, v, not right, n, p, min(16, os.cpu_count() or 1))      # x^T M (left) or M x (right)
+res = dict(workload=name, right=right, rows=M.nrows, cols=M.ncols, nnz=M.nnz, n=n, prime=str(p), iterations=ctx.iterations,
+           setup_s=round(t_setup, 2), solve_wall_s=round(wall, 2), device_s=round(dev_ms / 1e3, 2),
+           ms_per_iteration=round(dev_ms / max(ctx.iterations, 1), 4), final_check=dict(v_nonzero=nz, vtM_zero=zero),
+           host_verification=dict(v_nonzero=bool(v.any()), product_is_zero=bool(not chk.any())),
+           nonzero_columns=int((v.reshape(-1, n) != 0).any(axis=0).sum()))
+print(json.dumps(res))
