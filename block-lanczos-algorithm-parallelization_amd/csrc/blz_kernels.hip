@@ -220,7 +220,11 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 	while ((G << (split_log2 + 1)) <= 64 && (double)A.rows * (1 << split_log2) < 2.0 * c.num_cu * 8 * groups_per_block
 	       && avg / (1 << (split_log2 + 1)) >= 4.0)
 		split_log2++;
-	int per_cu = c.spmv_blocks_per_cu > 0 ? c.spmv_blocks_per_cu : (avg / (1 << split_log2) >= 12.0 ? 4 : 8);
+	/* (128-byte block rows out of an HBM-sized X are the exception: they want the full 8, measured on the
+	 * config-5 shape) */
+	const bool wide_rows_from_hbm = (size_t)G * sizeof(W) >= 128 && (double)A.cols * c.n * sizeof(W) > 256e6;
+	int per_cu = c.spmv_blocks_per_cu > 0 ? c.spmv_blocks_per_cu
+					      : ((avg / (1 << split_log2) >= 12.0 && !wide_rows_from_hbm) ? 4 : 8);
 	long long blocks = ((A.rows << split_log2) + groups_per_block - 1) / groups_per_block;
 	const long long cap = (long long)c.num_cu * per_cu;
 	if (blocks > cap)
