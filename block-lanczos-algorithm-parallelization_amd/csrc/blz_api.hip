@@ -343,10 +343,7 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 				c->inv[sd][(size_t)c->perm[sd][r]] = (int32_t)r;
 		}
 		std::vector<int32_t> ni((size_t)M->nnz), nj((size_t)M->nnz);
-		for (int64_t k = 0; k < M->nnz; k++) {
-			ni[(size_t)k] = c->perm[rs][(size_t)M->i[k]];
-			nj[(size_t)k] = c->perm[cs][(size_t)M->j[k]];
-		}
+		blz_coo_relabel(M, c->perm[rs].data(), c->perm[cs].data(), ni.data(), nj.data());
 		blz_coo R = *M;
 		R.i = ni.data();
 		R.j = nj.data();

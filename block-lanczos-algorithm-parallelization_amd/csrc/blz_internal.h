@@ -16,6 +16,8 @@ int blz_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)
  * g*stride + (r - b_g).  For one rank this is the identity. */
 void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t stride);
 
+void blz_coo_relabel(const blz_coo *M, const int32_t *row_perm, const int32_t *col_perm, int32_t *new_i, int32_t *new_j);
+
 /* Rows [r0, r1) of A as a standalone CSR (deep copy). */
 int blz_csr_slab(const blz_csr *A, int64_t r0, int64_t r1, blz_csr *out);
 

@@ -246,7 +246,7 @@ int blz_synth_coo(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int 
 		blz_coo_free(out);
 		return blz_fail(BLZ_ENOMEM, "blz_synth_coo: out of memory");
 	}
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (nnz > 200000)
 	for (int64_t r = 0; r < nrows; r++) {
 		const int64_t cnt = base + (r < extra);
 		int64_t at = r * base + (r < extra ? r : extra);
@@ -301,21 +301,33 @@ int blz_csr_from_coo(const blz_coo *M, int transpose, int pattern, blz_csr *out)
 	out->row_ptr = calloc((size_t)rows + 2, sizeof *out->row_ptr);
 	out->col_idx = malloc((size_t)(M->nnz ? M->nnz : 1) * sizeof *out->col_idx);
 	int ones = pattern != 0;
-	if (ones)
-		for (int64_t k = 0; k < M->nnz && ones; k++)
-			ones = (M->x[k] == 1);
+	if (ones) {
+		int64_t not_one = 0;
+#pragma omp parallel for schedule(static) reduction(+ : not_one) if (M->nnz > 200000)
+		for (int64_t k = 0; k < M->nnz; k++)
+			not_one += (M->x[k] != 1);
+		ones = (not_one == 0);
+	}
 	out->val = ones ? NULL : malloc((size_t)(M->nnz ? M->nnz : 1) * sizeof *out->val);
 	if (!out->row_ptr || !out->col_idx || (!ones && !out->val)) {
 		blz_csr_free(out);
 		return blz_fail(BLZ_ENOMEM, "blz_csr_from_coo: out of memory");
 	}
 	uint32_t *next = out->row_ptr + 1;	/* next[r] will become the start of row r */
-	for (int64_t k = 0; k < M->nnz; k++)
+	/* histogram, prefix sums, scatter -- the two passes over the entries run on all host cores (atomic counters;
+	 * the order of the entries inside a row is then arbitrary, which no result depends on) */
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
+	for (int64_t k = 0; k < M->nnz; k++) {
+#pragma omp atomic update
 		next[ri[k] + 1]++;
+	}
 	for (int64_t r = 0; r < rows; r++)
 		next[r + 1] += next[r];		/* next[r] = start(r), next[rows] = nnz */
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
 	for (int64_t k = 0; k < M->nnz; k++) {
-		const uint32_t at = next[ri[k]]++;
+		uint32_t at;
+#pragma omp atomic capture
+		at = next[ri[k]]++;
 		out->col_idx[at] = ci[k];
 		if (out->val)
 			out->val[at] = M->x[k];
@@ -368,6 +380,7 @@ void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t str
 {
 	if (parts == 1)
 		return;
+#pragma omp parallel for schedule(static) if (A->nnz > 200000)
 	for (int64_t k = 0; k < A->nnz; k++) {
 		const int64_t c = A->col_idx[k];
 		int lo = 0, hi = parts - 1;	/* largest g with bounds[g] <= c */
@@ -379,6 +392,23 @@ void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t str
 				hi = mid - 1;
 		}
 		A->col_idx[k] = (int32_t)(lo * stride + (c - bounds[lo]));
+	}
+}
+
+static inline void atomic_min_i32(int32_t *addr, int32_t v)
+{
+	int32_t cur = __atomic_load_n(addr, __ATOMIC_RELAXED);
+	while (v < cur && !__atomic_compare_exchange_n(addr, &cur, v, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED))
+		;
+}
+
+/* new_i[k] = row_perm[i[k]], new_j[k] = col_perm[j[k]] (all host cores) */
+void blz_coo_relabel(const blz_coo *M, const int32_t *row_perm, const int32_t *col_perm, int32_t *new_i, int32_t *new_j)
+{
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
+	for (int64_t k = 0; k < M->nnz; k++) {
+		new_i[k] = row_perm[M->i[k]];
+		new_j[k] = col_perm[M->j[k]];
 	}
 }
 
@@ -406,21 +436,21 @@ int blz_reorder(const blz_coo *M, int32_t *row_perm, int32_t *col_perm)
 	if (!key)
 		return blz_fail(BLZ_ENOMEM, "blz_reorder: out of memory");
 	/* rows by smallest column (rows without entries last) */
+#pragma omp parallel for schedule(static) if (M->nrows > 200000)
 	for (int64_t r = 0; r < M->nrows; r++)
 		key[r] = (int32_t)M->ncols;
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
 	for (int64_t k = 0; k < M->nnz; k++)
-		if (M->j[k] < key[M->i[k]])
-			key[M->i[k]] = M->j[k];
+		atomic_min_i32(&key[M->i[k]], M->j[k]);
 	int rc = sort_by_key(key, M->nrows, M->ncols, row_perm);
 	/* columns by smallest NEW row */
 	if (rc == BLZ_OK) {
+#pragma omp parallel for schedule(static) if (M->ncols > 200000)
 		for (int64_t c = 0; c < M->ncols; c++)
 			key[c] = (int32_t)M->nrows;
-		for (int64_t k = 0; k < M->nnz; k++) {
-			const int32_t nr = row_perm[M->i[k]];
-			if (nr < key[M->j[k]])
-				key[M->j[k]] = nr;
-		}
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
+		for (int64_t k = 0; k < M->nnz; k++)
+			atomic_min_i32(&key[M->j[k]], row_perm[M->i[k]]);
 		rc = sort_by_key(key, M->ncols, M->nrows, col_perm);
 	}
 	free(key);
