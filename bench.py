@@ -155,12 +155,12 @@ def main():
     bytes2 = spmv_alg_bytes(nnz2, loc_v, rows_t, n, word, pattern)
     # roofline kernel = k_spmv, the first SpMV of every step (the second one carries block_dot as its epilogue and is
     # listed under "kernels"); HIP-event spans on the solver's stream, collected inside blz_iterate
-    l1 = prof["spmv1"]["launches"]
-    t_spmv_ms = prof["spmv1"]["ms_total"] / max(l1, 1)
+    # (with several ranks a product is cut into column pieces that overlap the exchange: time per product, not per piece)
+    t_spmv_ms = prof["spmv1"]["ms_total"] / max(args.steps, 1)
     alg_bytes = bytes1
     achieved = alg_bytes / (t_spmv_ms * 1e-3) / 1e9
-    kernels = {k: dict(ms_mean=(v["ms_total"] / v["launches"]) if v["launches"] else None, launches=v["launches"])
-               for k, v in prof.items()}
+    kernels = {k: dict(ms_mean=(v["ms_total"] / args.steps) if v["launches"] else None, launches=v["launches"])
+               for k, v in prof.items()}     # ms_mean = per step (a step may issue several launches of one class)
     kernels["spmv1"]["alg_bytes"] = bytes1
     kernels["spmv2"]["alg_bytes"] = bytes2
     for k_ in ("spmv1", "spmv2"):

@@ -3,11 +3,13 @@
  * kernel sequencing, HIP-event timing and the RCCL exchange steps.
  *
  * HBM layout per context (one per GPU).  "side 0" = rows of v/Av/p, "side 1" = rows of tmp.
- *   blk[V], blk[AV], blk[P] : side 0, blk[TMP] : side 1.  Every block is stored in the rank-major
- *   padded layout  [rank g][stride rows][n words]  so that an in-place ncclAllGather of the slabs
- *   yields the operand a CSR slab indexes (its column indices are remapped on the host).  With one
- *   rank the layout degenerates to the reference's row-major N x n array.
- *   csr[0] = this rank's rows of M, csr[1] = this rank's rows of M^T.
+ *   slab[V], slab[AV], slab[P] : this rank's rows of side 0, slab[TMP] : its rows of side 1, row-major
+ *   rows x n, padded to `stride` rows.  With one rank these ARE the reference's N x n arrays.
+ *   gath[side] (only with nranks > 1): the all-gathered operand of a product, K = ag_chunks pieces:
+ *   [piece k][rank g][stride/K rows][n] -- ncclAllGather number k moves piece k of every slab and lands
+ *   contiguously, so the product on csr[t][k] (the entries whose columns lie in piece k) can run on the compute
+ *   stream while piece k+1 is still in flight on the exchange stream.
+ *   csr[0][k] / csr[1][k] = this rank's rows of M / M^T restricted to the columns of piece k.
  *   small  = [vtAv | vtAAv | winv | d | c | vtAvd], 6*n*n words;  ctl = DevCtl.
  */
 #include <dlfcn.h>
@@ -102,10 +104,16 @@ struct blz_ctx {
 	int64_t glob_rows[2] = { 0, 0 };		/* side 0: N, side 1: C */
 	int64_t first[2] = { 0, 0 }, count[2] = { 0, 0 }, stride[2] = { 0, 0 };
 	std::vector<int64_t> bounds[2];
-	DevCsr csr[2];
+	std::vector<DevCsr> csr[2];			/* column pieces of this rank's rows of M / M^T */
 	int row_side[2] = { 0, 1 };			/* side of the rows of csr[t] */
-	void *blk[4] = { nullptr, nullptr, nullptr, nullptr };
-	size_t blk_bytes = 0;
+	void *slab[4] = { nullptr, nullptr, nullptr, nullptr };
+	size_t slab_bytes = 0;
+	void *gath[2] = { nullptr, nullptr };		/* gathered operands (nranks > 1) */
+	int gath_holds[2] = { -1, -1 };			/* which block each one currently holds */
+	int ag_chunks = 0;				/* pieces per all-gather: BLZ_AG_CHUNKS, 0 = choose from the slab size */
+	hipStream_t xstream = nullptr;			/* exchange stream (all-gathers run beside the products) */
+	hipEvent_t ev_prod = nullptr;			/* the producer of the block to exchange has been enqueued */
+	std::vector<hipEvent_t> ev_piece;		/* piece k of the exchange has landed */
 	u64 *small = nullptr, *partial = nullptr;
 	int max_dot_blocks = 0;
 	DevCtl *ctl = nullptr;
@@ -124,7 +132,8 @@ struct blz_ctx {
 struct Span {
 	blz_ctx *c;
 	hipEvent_t b = nullptr;
-	Span(blz_ctx *ctx, int cls) : c(ctx)
+	hipStream_t st;
+	Span(blz_ctx *ctx, int cls, hipStream_t on = nullptr) : c(ctx), st(on ? on : ctx->stream)
 	{
 		if (!c->profiling)
 			return;
@@ -137,23 +146,25 @@ struct Span {
 				return;
 			}
 		}
-		(void)hipEventRecord(ev[0], c->stream);
+		(void)hipEventRecord(ev[0], st);
 		b = ev[1];
 		c->spans.push_back(ProfSpan{ cls, ev[0], ev[1] });
 	}
 	~Span()
 	{
 		if (b)
-			(void)hipEventRecord(b, c->stream);
+			(void)hipEventRecord(b, st);
 	}
 };
 
 static inline int side_of(int block) { return block == BLZ_TMP ? 1 : 0; }
 
-static inline char *slab_ptr(const blz_ctx *c, int block)
+static inline char *slab_ptr(const blz_ctx *c, int block) { return (char *)c->slab[block]; }
+
+/* the operand a product reads when its source is `block`: the slab itself on one rank, else the gathered copy */
+static inline const void *operand_ptr(const blz_ctx *c, int block)
 {
-	const int sd = side_of(block);
-	return (char *)c->blk[block] + (size_t)c->rank * c->stride[sd] * c->cfg.n * c->cfg.word;
+	return c->nranks == 1 ? c->slab[block] : c->gath[side_of(block)];
 }
 
 static void free_csr(DevCsr &A)
@@ -209,7 +220,12 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	c->reorder = !(nr && nr[0] == '1');
 	const char *nf = getenv("BLZ_NO_FUSE");
 	c->fuse_dot = !(nf && nf[0] == '1');
+	if (const char *ac = getenv("BLZ_AG_CHUNKS"))
+		if (atoi(ac) >= 1 && atoi(ac) <= 64)
+			c->ag_chunks = atoi(ac);
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+	HIPCHK(hipEventCreateWithFlags(&c->ev_prod, hipEventDisableTiming));
 	HIPCHK(hipEventCreate(&c->ev0));
 	HIPCHK(hipEventCreate(&c->ev1));
 	HIPCHK(hipMalloc(&c->small, small_words(n) * sizeof(u64)));
@@ -229,6 +245,8 @@ extern "C" void blz_destroy(blz_ctx *c)
 	hipSetDevice(c->device);
 	if (c->stream)
 		hipStreamSynchronize(c->stream);
+	if (c->xstream)
+		hipStreamSynchronize(c->xstream);
 	for (auto &sp : c->spans) {
 		hipEventDestroy(sp.a);
 		hipEventDestroy(sp.b);
@@ -237,10 +255,17 @@ extern "C" void blz_destroy(blz_ctx *c)
 		hipEventDestroy(e);
 	if (c->comm && g_rccl.CommDestroy)
 		g_rccl.CommDestroy(c->comm);
-	free_csr(c->csr[0]);
-	free_csr(c->csr[1]);
-	for (void *&b : c->blk)
+	for (int t = 0; t < 2; t++)
+		for (auto &A : c->csr[t])
+			free_csr(A);
+	for (void *&b : c->slab)
 		if (b) hipFree(b);
+	for (void *&b : c->gath)
+		if (b) hipFree(b);
+	for (auto &e : c->ev_piece)
+		hipEventDestroy(e);
+	if (c->ev_prod) hipEventDestroy(c->ev_prod);
+	if (c->xstream) hipStreamDestroy(c->xstream);
 	if (c->small) hipFree(c->small);
 	if (c->partial) hipFree(c->partial);
 	if (c->ctl) hipFree(c->ctl);
@@ -323,6 +348,19 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 	c->row_side[1] = right ? 0 : 1;		/* rows of M^T */
 
 	blz_csr slabs[2];
+	/* Pieces per exchange.  BLZ_AG_CHUNKS fixes it; otherwise up to 4 pieces of at least ~2 MB of the smaller
+	 * block's slab (below that the collectives are latency-bound and cutting them up only adds launches).
+	 * A single rank only cuts its products up when the collectives are forced on (tests). */
+	int K = 1;
+	if (nranks > 1 || c->force_comm) {
+		if (c->ag_chunks > 0) {
+			K = c->ag_chunks;
+		} else {
+			const int64_t rows = std::min(right ? M->ncols : M->nrows, right ? M->nrows : M->ncols) / nranks;
+			const int64_t slab_bytes = rows * c->cfg.n * c->cfg.word;
+			K = (int)std::max<int64_t>(1, std::min<int64_t>(4, slab_bytes / (2 << 20)));
+		}
+	}
 	c->bounds[0].assign((size_t)nranks + 1, 0);
 	c->bounds[1].assign((size_t)nranks + 1, 0);
 	int rc;
@@ -347,9 +385,9 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 		blz_coo R = *M;
 		R.i = ni.data();
 		R.j = nj.data();
-		rc = blz_shard_matrix(&R, right, rank, nranks, slabs, c->bounds[0].data(), c->bounds[1].data(), c->stride);
+		rc = blz_shard_matrix(&R, right, rank, nranks, K, slabs, c->bounds[0].data(), c->bounds[1].data(), c->stride);
 	} else {
-		rc = blz_shard_matrix(M, right, rank, nranks, slabs, c->bounds[0].data(), c->bounds[1].data(), c->stride);
+		rc = blz_shard_matrix(M, right, rank, nranks, K, slabs, c->bounds[0].data(), c->bounds[1].data(), c->stride);
 	}
 	if (rc != BLZ_OK)
 		return rc;
@@ -357,23 +395,57 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 		c->first[sd] = c->bounds[sd][rank];
 		c->count[sd] = c->bounds[sd][rank + 1] - c->bounds[sd][rank];
 	}
-	for (int t = 0; t < 2 && rc == BLZ_OK; t++)
-		rc = upload_csr(c, slabs[t], c->csr[t]);
+	for (int t = 0; t < 2; t++) {
+		for (auto &A : c->csr[t])
+			free_csr(A);
+		c->csr[t].assign((size_t)K, DevCsr{});
+	}
+	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
+		if (K == 1) {
+			rc = upload_csr(c, slabs[t], c->csr[t][0]);
+		} else {
+			/* columns are positions in the gathered operand of the opposite side: piece k = [k*w, (k+1)*w) */
+			const int cs = 1 - c->row_side[t];
+			const int64_t width = (c->stride[cs] / K) * nranks;
+			std::vector<blz_csr> piece((size_t)K);
+			rc = blz_csr_split_columns(&slabs[t], width, K, piece.data());
+			for (int k = 0; k < K && rc == BLZ_OK; k++)
+				rc = upload_csr(c, piece[(size_t)k], c->csr[t][(size_t)k]);
+			for (auto &pc : piece)
+				blz_csr_free(&pc);
+		}
+	}
 	blz_csr_free(&slabs[0]);
 	blz_csr_free(&slabs[1]);
 	if (rc != BLZ_OK)
 		return rc;
 
-	const int64_t rows_max = std::max(c->stride[0], c->stride[1]) * nranks;
-	const size_t bytes = (size_t)std::max<int64_t>(rows_max, 1) * c->cfg.n * c->cfg.word;
+	const int64_t slab_rows = std::max<int64_t>(std::max(c->stride[0], c->stride[1]), 1);
+	const size_t bytes = (size_t)slab_rows * c->cfg.n * c->cfg.word;
 	for (int b = 0; b < 4; b++) {
-		if (c->blk[b])
-			hipFree(c->blk[b]);
-		c->blk[b] = nullptr;
-		HIPCHK(hipMalloc(&c->blk[b], bytes));
-		HIPCHK(hipMemset(c->blk[b], 0, bytes));		/* sequential/lanczos_modp.c:617-622 */
+		if (c->slab[b])
+			hipFree(c->slab[b]);
+		c->slab[b] = nullptr;
+		HIPCHK(hipMalloc(&c->slab[b], bytes));
+		HIPCHK(hipMemset(c->slab[b], 0, bytes));		/* sequential/lanczos_modp.c:617-622 */
 	}
-	c->blk_bytes = bytes;
+	c->slab_bytes = bytes;
+	for (int sd = 0; sd < 2; sd++) {
+		if (c->gath[sd])
+			hipFree(c->gath[sd]);
+		c->gath[sd] = nullptr;
+		c->gath_holds[sd] = -1;
+		if (nranks > 1) {
+			const size_t gb = (size_t)std::max<int64_t>(c->stride[sd], 1) * nranks * c->cfg.n * c->cfg.word;
+			HIPCHK(hipMalloc(&c->gath[sd], gb));
+			HIPCHK(hipMemset(c->gath[sd], 0, gb));
+		}
+	}
+	while ((int)c->ev_piece.size() < K) {
+		hipEvent_t e;
+		HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		c->ev_piece.push_back(e);
+	}
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
 	c->host_ctl = DevCtl{};
 	c->have_matrix = true;
@@ -396,15 +468,22 @@ extern "C" int64_t blz_local_rows(const blz_ctx *c, int block, int64_t *first)
 
 extern "C" int64_t blz_local_nnz(const blz_ctx *c, int transpose)
 {
-	return (c && c->have_matrix) ? c->csr[transpose ? 1 : 0].nnz : -1;
+	if (!c || !c->have_matrix)
+		return -1;
+	int64_t nnz = 0;
+	for (const auto &A : c->csr[transpose ? 1 : 0])
+		nnz += A.nnz;
+	return nnz;
 }
 
 extern "C" int64_t blz_matrix_stream_bytes(const blz_ctx *c, int transpose)
 {
 	if (!c || !c->have_matrix)
 		return -1;
-	const DevCsr &A = c->csr[transpose ? 1 : 0];
-	return (A.rows + 1) * 4 + A.nnz * 4 + (A.val ? A.nnz * 4 : 0);
+	int64_t bytes = 0;
+	for (const auto &A : c->csr[transpose ? 1 : 0])
+		bytes += (A.rows + 1) * 4 + A.nnz * 4 + (A.val ? A.nnz * 4 : 0);
+	return bytes;
 }
 
 /* host u64 words -> device words of the context's width */
@@ -472,13 +551,28 @@ extern "C" int blz_set_block(blz_ctx *c, int block, const uint64_t *host)
 		to_solver_order(c, sd, host, tmp.data());
 		src = tmp.data();
 	}
+	HIPCHK(hipStreamSynchronize(c->xstream));
+	/* this rank's rows */
+	int rc = put_words(c, c->slab[block], src + c->first[sd] * n, c->count[sd] * n);
+	if (rc != BLZ_OK || c->nranks == 1)
+		return rc;
+	/* and, with several ranks, the whole gathered operand (an all-gather done by the caller): piece k of rank g
+	 * sits at (k * nranks + g) * piece rows */
+	const int K = (int)c->csr[0].size();
+	const int64_t piece = c->stride[sd] / K;
 	for (int g = 0; g < c->nranks; g++) {
 		const int64_t b0 = c->bounds[sd][g], cnt = c->bounds[sd][g + 1] - b0;
-		char *dst = (char *)c->blk[block] + (size_t)g * c->stride[sd] * n * c->cfg.word;
-		int rc = put_words(c, dst, src + b0 * n, cnt * n);
-		if (rc != BLZ_OK)
-			return rc;
+		for (int k = 0; k < K; k++) {
+			const int64_t q0 = (int64_t)k * piece, q1 = std::min<int64_t>(q0 + piece, cnt);
+			if (q1 <= q0)
+				break;
+			char *dst = (char *)c->gath[sd] + (size_t)(((int64_t)k * c->nranks + g) * piece) * n * c->cfg.word;
+			rc = put_words(c, dst, src + (b0 + q0) * n, (q1 - q0) * n);
+			if (rc != BLZ_OK)
+				return rc;
+		}
 	}
+	c->gath_holds[sd] = block;
 	return BLZ_OK;
 }
 
@@ -488,6 +582,7 @@ extern "C" int blz_get_block(blz_ctx *c, int block, uint64_t *host)
 	if (block < 0 || block > 3 || !host)
 		return blz_fail(BLZ_EINVAL, "blz_get_block: bad argument");
 	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipStreamSynchronize(c->xstream));
 	const int sd = side_of(block), n = c->cfg.n;
 	if (c->perm[sd].empty())
 		return get_words(c, host + c->first[sd] * n, slab_ptr(c, block), c->count[sd] * n);
@@ -558,8 +653,10 @@ extern "C" int blz_init_v(blz_ctx *c)
 {
 	NEED_MATRIX(c);
 	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipStreamSynchronize(c->xstream));
 	for (int b = 0; b < 4; b++)
-		HIPCHK(hipMemset(c->blk[b], 0, c->blk_bytes));
+		HIPCHK(hipMemset(c->slab[b], 0, c->slab_bytes));
+	c->gath_holds[0] = c->gath_holds[1] = -1;
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
 	c->host_ctl = DevCtl{};
 	/* :624-625: one sequential stream over the whole block in ORIGINAL row order; a rank keeps the rows it owns. */
@@ -583,38 +680,78 @@ extern "C" int blz_init_v(blz_ctx *c)
 
 /* ---- exchange steps (RCCL over xGMI).  No-ops on a single rank. ---- */
 
-static int allgather_block(blz_ctx *c, int block)
+static inline bool exchanging(const blz_ctx *c)
 {
-	if (c->external_exchange || (c->nranks == 1 && !(c->force_comm && c->comm)))
-		return BLZ_OK;
-	Span sp(c, block == BLZ_V ? PK_AG_V : PK_AG_T);
-	if (!c->comm)
-		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
-	const int sd = side_of(block);
-	const size_t bytes = (size_t)c->stride[sd] * c->cfg.n * c->cfg.word;
-	NCCLCHK(g_rccl.AllGather(slab_ptr(c, block), c->blk[block], bytes, ncclUint8, c->comm, c->stream));
-	return BLZ_OK;
+	return !c->external_exchange && (c->nranks > 1 || (c->force_comm && c->comm));
 }
 
 static int allreduce_dots(blz_ctx *c)
 {
-	if (c->external_exchange || (c->nranks == 1 && !(c->force_comm && c->comm)))
+	if (!exchanging(c))
 		return BLZ_OK;
 	if (!c->comm)
 		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
 	Span sp(c, PK_AR);
-	/* residues < p < 2^62 and at most 4 ... 8 ranks: for p < 2^61 the u64 sum cannot wrap; the
+	/* residues < p and nranks * p <= 2^64 (checked in blz_set_matrix): the u64 sum cannot wrap; the
 	 * semi_inverse kernel reduces it mod p.  (mpi/lanczos_modp.c:1209-1247 does this by hand.) */
 	NCCLCHK(g_rccl.AllReduce(c->small, c->small, (size_t)2 * c->cfg.n * c->cfg.n, ncclUint64, ncclSum, c->comm,
 				 c->stream));
 	return BLZ_OK;
 }
 
+/*
+ * One product of the iteration: slab[dst] = (transpose ? M^T : M)[this rank's rows] * block `src`, with the
+ * exchange of `src` pipelined against it.  The exchange stream all-gathers piece k of every rank's slab into
+ * gath[side]; the compute stream waits for piece k only, then multiplies by csr[transpose][k] (entries whose
+ * columns lie in piece k), accumulating into slab[dst] from the second piece on.  With K pieces the product hides
+ * all but 1/K of itself behind the exchange; K = 1 is one all-gather followed by one product.
+ * with_dot: the last piece carries block_dot_products as its epilogue (second product only); *nb = partial rows.
+ */
+static int enqueue_product(blz_ctx *c, int transpose, int src, int dst, bool with_dot, int *nb)
+{
+	const int K = (int)c->csr[transpose].size(), sd = side_of(src);
+	const bool xchg = exchanging(c);
+	const int cls = transpose == !c->right ? PK_SPMV1 : PK_SPMV2;
+	if (xchg) {
+		if (!c->comm)
+			return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
+		/* the exchange may start once everything enqueued so far (the producer of `src`, and every earlier
+		 * reader of the gathered buffer it overwrites) has run */
+		HIPCHK(hipEventRecord(c->ev_prod, c->stream));
+		HIPCHK(hipStreamWaitEvent(c->xstream, c->ev_prod, 0));
+		const size_t piece = (size_t)(c->stride[sd] / K) * c->cfg.n * c->cfg.word;
+		char *recv = c->nranks == 1 ? (char *)c->slab[src] : (char *)c->gath[sd];	/* 1 rank: in place */
+		for (int k = 0; k < K; k++) {
+			{
+				Span sp(c, src == BLZ_V ? PK_AG_V : PK_AG_T, c->xstream);
+				NCCLCHK(g_rccl.AllGather((char *)c->slab[src] + (size_t)k * piece,
+							 recv + (size_t)k * c->nranks * piece, piece, ncclUint8, c->comm,
+							 c->xstream));
+			}
+			HIPCHK(hipEventRecord(c->ev_piece[(size_t)k], c->xstream));
+		}
+		c->gath_holds[sd] = src;
+	} else if (c->nranks > 1 && c->gath_holds[sd] != src) {
+		return blz_fail(BLZ_EINVAL, "external-exchange mode: block %d has not been gathered (blz_set_block)", src);
+	}
+	const void *X = operand_ptr(c, src);
+	for (int k = 0; k < K; k++) {
+		if (xchg)
+			HIPCHK(hipStreamWaitEvent(c->stream, c->ev_piece[(size_t)k], 0));
+		Span sp(c, cls);
+		const DevCsr &A = c->csr[transpose][(size_t)k];
+		if (with_dot && k == K - 1)
+			HIPCHK(launch_spmv_dot(c->cfg, A, X, slab_ptr(c, dst), slab_ptr(c, BLZ_V), k > 0, c->partial,
+					       c->max_dot_blocks, nb, c->ctl, c->stream));
+		else
+			HIPCHK(launch_spmv(c->cfg, A, X, slab_ptr(c, dst), k > 0, c->ctl, c->stream));
+	}
+	return BLZ_OK;
+}
+
 static int enqueue_spmv(blz_ctx *c, int transpose, int src, int dst)
 {
-	Span sp(c, transpose == !c->right ? PK_SPMV1 : PK_SPMV2);
-	HIPCHK(launch_spmv(c->cfg, c->csr[transpose], c->blk[src], slab_ptr(c, dst), c->ctl, c->stream));
-	return BLZ_OK;
+	return enqueue_product(c, transpose, src, dst, false, nullptr);
 }
 
 static int enqueue_dot(blz_ctx *c)
@@ -707,23 +844,17 @@ extern "C" int blz_orthogonalize(blz_ctx *c)
 static int enqueue_iteration(blz_ctx *c)
 {
 	int rc;
-	if ((rc = allgather_block(c, BLZ_V)) != BLZ_OK) return rc;
-	if ((rc = enqueue_spmv(c, !c->right, BLZ_V, BLZ_TMP)) != BLZ_OK) return rc;	/* :635 */
-	if ((rc = allgather_block(c, BLZ_TMP)) != BLZ_OK) return rc;
-	if (c->fuse_dot && spmv_dot_supported(c->cfg) && c->csr[c->right].rows > 0) {
+	if ((rc = enqueue_product(c, !c->right, BLZ_V, BLZ_TMP, false, nullptr)) != BLZ_OK) return rc;	/* :635 */
+	if (c->fuse_dot && spmv_dot_supported(c->cfg) && c->count[0] > 0) {
 		int nb = 0;							/* :636 + :640 in one kernel */
-		{
-			Span sp(c, PK_SPMV2);
-			HIPCHK(launch_spmv_dot(c->cfg, c->csr[c->right], c->blk[BLZ_TMP], slab_ptr(c, BLZ_AV), slab_ptr(c, BLZ_V),
-					       c->partial, c->max_dot_blocks, &nb, c->ctl, c->stream));
-		}
+		if ((rc = enqueue_product(c, c->right, BLZ_TMP, BLZ_AV, true, &nb)) != BLZ_OK) return rc;
 		{
 			Span sp(c, PK_DOT);
 			HIPCHK(launch_dot_finalize(c->cfg, c->partial, nb, c->small, c->ctl, c->stream));
 		}
 		if ((rc = allreduce_dots(c)) != BLZ_OK) return rc;
 	} else {
-		if ((rc = enqueue_spmv(c, c->right, BLZ_TMP, BLZ_AV)) != BLZ_OK) return rc;	/* :636 */
+		if ((rc = enqueue_product(c, c->right, BLZ_TMP, BLZ_AV, false, nullptr)) != BLZ_OK) return rc;	/* :636 */
 		if ((rc = enqueue_dot(c)) != BLZ_OK) return rc;				/* :640 */
 	}
 	{
@@ -861,6 +992,7 @@ extern "C" int blz_sync(blz_ctx *c)
 		return blz_fail(BLZ_EINVAL, "blz_sync: NULL context");
 	HIPCHK(hipSetDevice(c->device));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipStreamSynchronize(c->xstream));
 	return BLZ_OK;
 }
 

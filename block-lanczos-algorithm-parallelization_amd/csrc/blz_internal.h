@@ -11,10 +11,13 @@ extern "C" {
 /* printf-style; returns `code` so that callers can `return blz_fail(BLZ_EINVAL, "...")`. */
 int blz_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
-/* Column indices of a CSR slab are rewritten from global rows of the source block to positions in
- * the rank-major padded ("gathered") layout: row r of rank g's slab [b_g, b_{g+1}) lives at
- * g*stride + (r - b_g).  For one rank this is the identity. */
-void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t stride);
+/* Column indices of a CSR slab are rewritten from global rows of the source block to positions in the
+ * gathered operand: a slab of `chunks` pieces of `piece` rows each; row q of rank g's slab lives at
+ *     (q / piece) * (parts * piece) + g * piece + (q % piece)
+ * i.e. piece-major, rank-major inside a piece, so that all-gather number k of equal pieces lands contiguously.
+ * With chunks == 1 this is the rank-major padded layout; for one rank it is the identity. */
+void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t piece, int chunks);
+int blz_csr_split_columns(const blz_csr *A, int64_t width, int chunks, blz_csr *out);
 
 void blz_coo_relabel(const blz_coo *M, const int32_t *row_perm, const int32_t *col_perm, int32_t *new_i, int32_t *new_j);
 

@@ -33,13 +33,13 @@ struct KernelCfg {
 
 /* Y[rows x n] = A * X, X addressed through A.col_idx (row-major, n words per row).
  * sequential/lanczos_modp.c:266-287 */
-hipError_t launch_spmv(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const DevCtl *ctl,
-		       hipStream_t s);
+hipError_t launch_spmv(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, int accum, const DevCtl *ctl,
+		       hipStream_t s);	/* accum != 0: Y = (Y + A*X) mod p (one piece of a column-chunked product) */
 
 /* Y = A*X with block_dot_products(V_slab, Y) as the epilogue (n in {1,2,4,8,16} only): one partial row per block. */
 bool spmv_dot_supported(const KernelCfg &c);
-hipError_t launch_spmv_dot(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const void *Vd, u64 *partial,
-			   int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s);
+hipError_t launch_spmv_dot(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const void *Vd, int accum,
+			   u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s);
 
 /* partial[b][0..n*n) = sum over block b's rows of v^T Av, partial[b][n*n..2n*n) = Av^T Av.
  * sequential/lanczos_modp.c:443-453.  Returns the number of partial rows written via *nblocks. */

@@ -153,7 +153,7 @@ template <typename W, int G, int MERS>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
        const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, long long rows, int n, int split_log2,
-       ModP m, const DevCtl *__restrict__ ctl)
+       int accum, ModP m, const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
@@ -190,21 +190,27 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 		spmv_accumulate<W>(acc, k, e, ci, va, spal, X, n, xl);
 		for (int off = G; off < (G << split_log2); off <<= 1)
 			acc_add_acc(acc, shfl_xor64(acc.lo, off), shfl_xor64(acc.hi, off));
-		if (lane < n && part == 0)
+		if (lane < n && part == 0) {
+			if (accum)		/* column-chunked product: this launch adds to what earlier pieces left in Y */
+				acc_add(acc, Y[(size_t)r * n + lane]);
 			Y[(size_t)r * n + lane] = (W)acc_reduce<MERS>(acc, m);
+		}
 	}
 	__syncthreads();
 	const int nh = hl.cnt < HEAVY_MAX ? hl.cnt : HEAVY_MAX;
 	for (int h = 0; h < nh; h++) {
 		const long long r = hl.rows[h];
-		const Acc acc = heavy_row_sum<W, G>(r, rp, ci, va, spal, X, n, xl, slices);
-		if (threadIdx.x < G && lane < n)
+		Acc acc = heavy_row_sum<W, G>(r, rp, ci, va, spal, X, n, xl, slices);
+		if (threadIdx.x < G && lane < n) {
+			if (accum)
+				acc_add(acc, Y[(size_t)r * n + lane]);
 			Y[(size_t)r * n + lane] = (W)acc_reduce<MERS>(acc, m);
+		}
 	}
 }
 
 template <typename W, int MERS>
-static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const DevCtl *ctl,
+static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, int accum, const DevCtl *ctl,
 				hipStream_t s)
 {
 	if (A.rows == 0)
@@ -232,7 +238,7 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 #define SPMV_CASE(GG)                                                                                             \
 	case GG:                                                                                                  \
 		hipLaunchKernelGGL((k_spmv<W, GG, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr,  \
-				   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, c.m, ctl); \
+				   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, accum, c.m, ctl); \
 		break;
 	switch (G) {
 		SPMV_CASE(1)
@@ -249,14 +255,14 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 	return hipGetLastError();
 }
 
-hipError_t launch_spmv(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const DevCtl *ctl,
+hipError_t launch_spmv(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, int accum, const DevCtl *ctl,
 		       hipStream_t s)
 {
 	if (c.word == 4)
-		return c.mers == 31 ? spmv_dispatch<u32, 31>(c, A, (const u32 *)X, (u32 *)Y, ctl, s)
-				    : spmv_dispatch<u32, 0>(c, A, (const u32 *)X, (u32 *)Y, ctl, s);
-	return c.mers == 61 ? spmv_dispatch<u64, 61>(c, A, (const u64 *)X, (u64 *)Y, ctl, s)
-			    : spmv_dispatch<u64, 0>(c, A, (const u64 *)X, (u64 *)Y, ctl, s);
+		return c.mers == 31 ? spmv_dispatch<u32, 31>(c, A, (const u32 *)X, (u32 *)Y, accum, ctl, s)
+				    : spmv_dispatch<u32, 0>(c, A, (const u32 *)X, (u32 *)Y, accum, ctl, s);
+	return c.mers == 61 ? spmv_dispatch<u64, 61>(c, A, (const u64 *)X, (u64 *)Y, accum, ctl, s)
+			    : spmv_dispatch<u64, 0>(c, A, (const u64 *)X, (u64 *)Y, accum, ctl, s);
 }
 
 /* --------------------------------------------------------------------- block_dot_products */
@@ -450,7 +456,7 @@ template <typename W, int MERS, int NT>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
 	   const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
-	   long long rows, ModP m, u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
+	   long long rows, int accum, ModP m, u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
@@ -478,6 +484,8 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 		Acc acc;
 		acc_zero(acc);
 		spmv_accumulate<W>(acc, k, e, ci, va, spal, X, NT, lane);
+		if (accum)
+			acc_add(acc, Y[(size_t)r * NT + lane]);
 		const u64 y = acc_reduce<MERS>(acc, m);
 		Y[(size_t)r * NT + lane] = (W)y;
 		ds.row(vi, y, lane, gbase, m);
@@ -486,8 +494,10 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 	const int nh = hl.cnt < HEAVY_MAX ? hl.cnt : HEAVY_MAX;
 	for (int h = 0; h < nh; h++) {
 		const long long r = hl.rows[h];
-		const Acc acc = heavy_row_sum<W, NT>(r, rp, ci, va, spal, X, NT, lane, slices);
+		Acc acc = heavy_row_sum<W, NT>(r, rp, ci, va, spal, X, NT, lane, slices);
 		if (t < NT) {
+			if (accum)
+				acc_add(acc, Y[(size_t)r * NT + lane]);
 			const u64 y = acc_reduce<MERS>(acc, m);
 			Y[(size_t)r * NT + lane] = (W)y;
 			ds.row(Vd[(size_t)r * NT + lane], y, lane, gbase, m);
@@ -497,8 +507,8 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 }
 
 template <typename W, int MERS>
-static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, u64 *partial,
-				    int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
+static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum,
+				    u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
 {
 	const long long gpb = BLOCK / c.n;
 	long long blocks = (A.rows + gpb - 1) / gpb;
@@ -510,7 +520,7 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 #define SPMV_DOT(NN)                                                                                                \
 	case NN:                                                                                                    \
 		hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
-				   A.val, A.palette, X, Y, Vd, (long long)A.rows, c.m, partial, ctl);               \
+				   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, c.m, partial, ctl);        \
 		break;
 	switch (c.n) {
 		SPMV_DOT(1)
@@ -530,14 +540,14 @@ bool spmv_dot_supported(const KernelCfg &c)
 	return c.n == 1 || c.n == 2 || c.n == 4 || c.n == 8 || c.n == 16;
 }
 
-hipError_t launch_spmv_dot(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const void *Vd, u64 *partial,
-			   int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
+hipError_t launch_spmv_dot(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const void *Vd, int accum,
+			   u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
 {
 	if (c.word == 4)
-		return c.mers == 31 ? spmv_dot_dispatch<u32, 31>(c, A, (const u32 *)X, (u32 *)Y, (const u32 *)Vd, partial, max_blocks, nblocks, ctl, s)
-				    : spmv_dot_dispatch<u32, 0>(c, A, (const u32 *)X, (u32 *)Y, (const u32 *)Vd, partial, max_blocks, nblocks, ctl, s);
-	return c.mers == 61 ? spmv_dot_dispatch<u64, 61>(c, A, (const u64 *)X, (u64 *)Y, (const u64 *)Vd, partial, max_blocks, nblocks, ctl, s)
-			    : spmv_dot_dispatch<u64, 0>(c, A, (const u64 *)X, (u64 *)Y, (const u64 *)Vd, partial, max_blocks, nblocks, ctl, s);
+		return c.mers == 31 ? spmv_dot_dispatch<u32, 31>(c, A, (const u32 *)X, (u32 *)Y, (const u32 *)Vd, accum, partial, max_blocks, nblocks, ctl, s)
+				    : spmv_dot_dispatch<u32, 0>(c, A, (const u32 *)X, (u32 *)Y, (const u32 *)Vd, accum, partial, max_blocks, nblocks, ctl, s);
+	return c.mers == 61 ? spmv_dot_dispatch<u64, 61>(c, A, (const u64 *)X, (u64 *)Y, (const u64 *)Vd, accum, partial, max_blocks, nblocks, ctl, s)
+			    : spmv_dot_dispatch<u64, 0>(c, A, (const u64 *)X, (u64 *)Y, (const u64 *)Vd, accum, partial, max_blocks, nblocks, ctl, s);
 }
 
 template <typename W, int MERS>

@@ -376,7 +376,7 @@ int blz_csr_slab(const blz_csr *A, int64_t r0, int64_t r1, blz_csr *out)
 	return BLZ_OK;
 }
 
-void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t stride)
+void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t piece, int chunks)
 {
 	if (parts == 1)
 		return;
@@ -391,9 +391,52 @@ void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t str
 			else
 				hi = mid - 1;
 		}
-		A->col_idx[k] = (int32_t)(lo * stride + (c - bounds[lo]));
+		const int64_t q = c - bounds[lo];	/* row inside rank lo's slab */
+		(void)chunks;
+		A->col_idx[k] = (int32_t)((q / piece) * (parts * piece) + lo * piece + (q % piece));
 	}
 }
+
+/* Entries of A whose column lies in [k*width, (k+1)*width) become out[k] (same rows): the column-chunked form the
+ * pipelined exchange multiplies piece by piece. */
+int blz_csr_split_columns(const blz_csr *A, int64_t width, int chunks, blz_csr *out)
+{
+	memset(out, 0, (size_t)chunks * sizeof *out);
+	for (int k = 0; k < chunks; k++) {
+		out[k].rows = A->rows;
+		out[k].cols = A->cols;
+		out[k].row_ptr = calloc((size_t)A->rows + 1, sizeof(uint32_t));
+		if (!out[k].row_ptr)
+			return blz_fail(BLZ_ENOMEM, "blz_csr_split_columns: out of memory");
+	}
+	for (int64_t r = 0; r < A->rows; r++)
+		for (uint32_t e = A->row_ptr[r]; e < A->row_ptr[r + 1]; e++)
+			out[A->col_idx[e] / width].row_ptr[r + 1]++;
+	for (int k = 0; k < chunks; k++) {
+		for (int64_t r = 0; r < A->rows; r++)
+			out[k].row_ptr[r + 1] += out[k].row_ptr[r];
+		out[k].nnz = out[k].row_ptr[A->rows];
+		out[k].col_idx = malloc((size_t)(out[k].nnz ? out[k].nnz : 1) * sizeof(int32_t));
+		out[k].val = A->val ? malloc((size_t)(out[k].nnz ? out[k].nnz : 1) * sizeof(uint32_t)) : NULL;
+		if (!out[k].col_idx || (A->val && !out[k].val))
+			return blz_fail(BLZ_ENOMEM, "blz_csr_split_columns: out of memory");
+	}
+	uint32_t *fill = calloc((size_t)chunks, sizeof *fill);
+	for (int64_t r = 0; r < A->rows; r++) {
+		for (int k = 0; k < chunks; k++)
+			fill[k] = out[k].row_ptr[r];
+		for (uint32_t e = A->row_ptr[r]; e < A->row_ptr[r + 1]; e++) {
+			const int k = (int)(A->col_idx[e] / width);
+			out[k].col_idx[fill[k]] = A->col_idx[e];
+			if (A->val)
+				out[k].val[fill[k]] = A->val[e];
+			fill[k]++;
+		}
+	}
+	free(fill);
+	return BLZ_OK;
+}
+
 
 static inline void atomic_min_i32(int32_t *addr, int32_t v)
 {
@@ -457,10 +500,10 @@ int blz_reorder(const blz_coo *M, int32_t *row_perm, int32_t *col_perm)
 	return rc;
 }
 
-int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, blz_csr slabs[2], int64_t *bounds0,
+int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, int chunks, blz_csr slabs[2], int64_t *bounds0,
 		     int64_t *bounds1, int64_t stride[2])
 {
-	if (!M || !slabs || !bounds0 || !bounds1 || !stride || nranks < 1 || rank < 0 || rank >= nranks)
+	if (!M || !slabs || !bounds0 || !bounds1 || !stride || nranks < 1 || rank < 0 || rank >= nranks || chunks < 1)
 		return blz_fail(BLZ_EINVAL, "blz_shard_matrix: bad argument");
 	memset(slabs, 0, 2 * sizeof slabs[0]);
 	blz_csr full[2];
@@ -481,7 +524,7 @@ int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, blz_csr 
 		for (int g = 0; g < nranks; g++)
 			if (bounds[sd][g + 1] - bounds[sd][g] > mx)
 				mx = bounds[sd][g + 1] - bounds[sd][g];
-		stride[sd] = mx;
+		stride[sd] = (mx + chunks - 1) / chunks * chunks;	/* slab rows, padded to a whole number of pieces */
 	}
 	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
 		const int rs = row_side[t], cs = 1 - rs;
@@ -491,7 +534,7 @@ int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, blz_csr 
 		} else {
 			rc = blz_csr_slab(&full[t], bounds[rs][rank], bounds[rs][rank + 1], &slabs[t]);
 			if (rc == BLZ_OK) {
-				blz_remap_columns(&slabs[t], bounds[cs], nranks, stride[cs]);
+				blz_remap_columns(&slabs[t], bounds[cs], nranks, stride[cs] / chunks, chunks);
 				slabs[t].cols = stride[cs] * nranks;
 			}
 		}

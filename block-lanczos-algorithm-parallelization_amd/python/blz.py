@@ -132,13 +132,14 @@ def _partition(A, parts):
     return list(b)
 
 
-def shard_matrix(M, right, rank, nranks):
+def shard_matrix(M, right, rank, nranks, chunks=1):
     """blz_shard_matrix(): the slabs, bounds and strides rank `rank` of `nranks` works with (host only)."""
     slabs = (Csr * 2)()
     b0 = (C.c_int64 * (nranks + 1))()
     b1 = (C.c_int64 * (nranks + 1))()
     stride = (C.c_int64 * 2)()
-    check(lib().blz_shard_matrix(C.byref(M.c), C.c_int(int(right)), C.c_int(rank), C.c_int(nranks), slabs, b0, b1, stride))
+    check(lib().blz_shard_matrix(C.byref(M.c), C.c_int(int(right)), C.c_int(rank), C.c_int(nranks), C.c_int(chunks), slabs,
+                                 b0, b1, stride))
     out = []
     for A in slabs:
         rp = np.ctypeslib.as_array(A.row_ptr, (A.rows + 1,)).copy()
@@ -146,7 +147,7 @@ def shard_matrix(M, right, rank, nranks):
         va = np.ctypeslib.as_array(A.val, (max(A.nnz, 1),))[:A.nnz].copy() if A.val else np.ones(A.nnz, np.uint32)
         out.append(dict(rows=int(A.rows), cols=int(A.cols), nnz=int(A.nnz), row_ptr=rp, col_idx=ci, val=va))
         lib().blz_csr_free(C.byref(A))
-    return dict(slabs=out, bounds=[list(b0), list(b1)], stride=list(stride))
+    return dict(slabs=out, bounds=[list(b0), list(b1)], stride=list(stride), chunks=chunks if nranks > 1 else 1)
 
 
 def reorder(M):

@@ -106,13 +106,15 @@ int blz_reorder(const blz_coo *M, int32_t *row_perm, int32_t *col_perm);
 /* What rank `rank` of `nranks` keeps of M for the solve (right=0: x*M=0, right=1: M*x=0).
  * "Side 0" is the row space of v/Av/p, "side 1" that of tmp (sequential/lanczos_modp.c:592-593).
  *   bounds0/bounds1 [nranks+1]  nnz-balanced row partition of each side
- *   stride[2]                   largest slab of each side: blocks are kept in the rank-major padded
- *                               layout  position(row r of rank g) = g*stride + (r - bounds[g])
- *                               so that an in-place all-gather of equal-sized slabs rebuilds a block
- *   slabs[0] = this rank's rows of M, slabs[1] = its rows of M^T, column indices already rewritten
- *              to positions in the padded layout of the opposite side (identity when nranks == 1).
+ *   stride[2]                   rows of a (padded) slab of each side, a multiple of `chunks`
+ *   slabs[0] = this rank's rows of M, slabs[1] = its rows of M^T, column indices already rewritten to positions
+ *              in the gathered operand of the opposite side:  with piece = stride/chunks, row q of rank g's slab
+ *              sits at  (q / piece) * (nranks * piece) + g * piece + (q % piece)  -- piece-major, so that
+ *              all-gather number k (piece k of every slab) lands contiguously and the product can start on it
+ *              while piece k+1 is in flight.  chunks = 1 gives the plain rank-major padded layout
+ *              g * stride + q; one rank gives the identity.
  * This is the whole multi-GPU data layout; blz_set_matrix uploads exactly these slabs. */
-int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, blz_csr slabs[2],
+int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, int chunks, blz_csr slabs[2],
 		     int64_t *bounds0, int64_t *bounds1, int64_t stride[2]);
 
 /* rng_state/random64(), sequential/lanczos_modp.c:67-87, and the initialisation
@@ -237,7 +239,10 @@ int blz_profile_read(blz_ctx *ctx, double ms_sum[BLZ_PROFILE_CLASSES], int64_t l
 int blz_set_exchange_mode(blz_ctx *ctx, int external);
 
 /* Multi-GPU (one process per GPU).  id_bytes = ncclUniqueId from blz_comm_unique_id() on rank 0,
- * broadcast by the caller (bench.py uses torch.distributed for that and nothing else). */
+ * broadcast by the caller (bench.py uses torch.distributed for that and nothing else).  Call blz_comm_init before
+ * blz_set_matrix.  Inside blz_iterate every product is pipelined against the exchange of its operand: the block is
+ * all-gathered in K pieces on a second stream and the product runs piece by piece behind it (K = up to 4 pieces of
+ * >= 2 MB per slab, or BLZ_AG_CHUNKS). */
 int blz_comm_unique_id(void *id_out, size_t id_bytes);	/* needs id_bytes >= 128 */
 int blz_comm_init(blz_ctx *ctx, const void *id, size_t id_bytes, int rank, int nranks);
 

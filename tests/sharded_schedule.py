@@ -23,8 +23,8 @@ def slab_as_coo(slab):
     return orc.Matrix(rows, slab["cols"], ri, slab["col_idx"], slab["val"])
 
 
-def run_rank(M, prime, n, right, rank, world, exchange, max_iters=10 ** 9):
-    sh = blz.shard_matrix(M, right, rank, world)
+def run_rank(M, prime, n, right, rank, world, exchange, max_iters=10 ** 9, chunks=1):
+    sh = blz.shard_matrix(M, right, rank, world, chunks)
     b0, b1 = sh["bounds"]
     s0, s1 = sh["stride"]
     first0, cnt0 = b0[rank], b0[rank + 1] - b0[rank]
@@ -42,12 +42,17 @@ def run_rank(M, prime, n, right, rank, world, exchange, max_iters=10 ** 9):
         out[:x.size] = x
         return out
 
+    def gathered(x, stride):
+        """all-gather of the padded slabs, laid out as the product wants it: [piece k][rank g][stride/chunks rows]"""
+        allg = exchange.allgather(padded(x, stride))                      # rank-major: [g][stride]
+        return allg.reshape(world, chunks, stride // chunks, n).transpose(1, 0, 2, 3).reshape(-1).copy()
+
     its = 0
     tmp = np.zeros(cnt1 * n, dtype=np.uint64)
     while its < max_iters:
-        vg = exchange.allgather(padded(v, s0))
+        vg = gathered(v, s0)
         tmp = orc.spmv(A1, vg, False, n, prime)
-        tg = exchange.allgather(padded(tmp, s1))
+        tg = gathered(tmp, s1)
         Av = orc.spmv(A2, tg, False, n, prime)
         a, b = orc.block_dot(cnt0, Av, v, n, prime)
         tot = exchange.allreduce_sum(np.concatenate([a, b]))

@@ -69,12 +69,13 @@ def sharded_solve(M, p, n, right, world, max_iters):
             c.close()
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (8, 1), (2, 4), (3, 3), (8, 2)])
 @pytest.mark.parametrize("name,p,n,right,iters", [
     ("rand300x200", P61, 8, False, 10 ** 9), ("rand300x200", 65537, 4, True, 10 ** 9),
     ("wide120x260", 2147483647, 4, True, 10 ** 9), ("rand3000x2000", P61, 8, False, 8),
     ("rand3000x2000", 1073741789, 16, True, 5)])
-def test_rank_local_kernels_with_emulated_exchange(name, p, n, right, iters, world):
+def test_rank_local_kernels_with_emulated_exchange(monkeypatch, name, p, n, right, iters, world, chunks):
+    monkeypatch.setenv("BLZ_AG_CHUNKS", str(chunks))     # pieces per all-gather = column pieces of every product
     path = os.path.join(GOLDEN, name + ".mtx")
     M, Mo = blz.Matrix.load(path, p), orc.Matrix.load(path, p)
     want = orc.block_lanczos(Mo, n, p, right=right, stop_after=iters if iters < 10 ** 8 else -1)
@@ -111,8 +112,10 @@ def test_multi_rank_context_without_communicator_fails_loudly():
         assert e.value.code == blz.ECOMM
 
 
-def test_rccl_plumbing_on_one_rank(monkeypatch):
+@pytest.mark.parametrize("chunks", [1, 4])
+def test_rccl_plumbing_on_one_rank(monkeypatch, chunks):
     monkeypatch.setenv("BLZ_FORCE_COMM", "1")
+    monkeypatch.setenv("BLZ_AG_CHUNKS", str(chunks))
     p, n = P61, 8
     path = os.path.join(GOLDEN, "rand3000x2000.mtx")
     M, Mo = blz.Matrix.load(path, p), orc.Matrix.load(path, p)
@@ -125,7 +128,8 @@ def test_rccl_plumbing_on_one_rank(monkeypatch):
         c.profile(True)
         c.iterate(6)
         prof = c.profile_read()
-        assert prof["allgather_v"]["launches"] == 6 and prof["allgather_tmp"]["launches"] == 6
+        assert prof["allgather_v"]["launches"] == 6 * chunks and prof["allgather_tmp"]["launches"] == 6 * chunks
+        assert prof["spmv1"]["launches"] == 6 * chunks and prof["spmv2"]["launches"] == 6 * chunks
         assert prof["allreduce"]["launches"] == 6
         want = orc.block_lanczos(Mo, n, p, stop_after=6)
         assert np.array_equal(c.get_block(blz.V), want["v"])

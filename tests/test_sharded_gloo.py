@@ -44,7 +44,7 @@ class GlooExchange:
         return t.numpy().view(np.uint64).copy()
 
 
-def _worker(rank, world, port, case, q):
+def _worker(rank, world, port, case, q, chunks=1):
     sys.path[:0] = [HERE, os.path.join(os.path.dirname(HERE), "oracle"),
                     os.path.join(os.path.dirname(HERE), "block-lanczos-algorithm-parallelization_amd", "python")]
     import blz
@@ -53,7 +53,7 @@ def _worker(rank, world, port, case, q):
     try:
         name, prime, n, right, iters = case
         M = blz.Matrix.load(os.path.join(GOLDEN, name + ".mtx"), prime)
-        res = ss.run_rank(M, prime, n, right, rank, world, GlooExchange(world), max_iters=iters)
+        res = ss.run_rank(M, prime, n, right, rank, world, GlooExchange(world), max_iters=iters, chunks=chunks)
         q.put((rank, res["first"], res["count"], res["iterations"], res["v"], res["p"], res["bounds"], res["stride"]))
         dist.barrier()
     finally:
@@ -65,15 +65,17 @@ CASES = [("rand300x200", (1 << 61) - 1, 8, False, 10 ** 9), ("rand300x200", 6553
          ("rand3000x2000", (1 << 61) - 1, 8, False, 12)]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (2, 4), (3, 3)])
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-p{c[1]}-n{c[2]}-{'R' if c[3] else 'L'}" for c in CASES])
-def test_sharded_schedule_over_gloo_matches_oracle(case, world):
+def test_sharded_schedule_over_gloo_matches_oracle(case, world, chunks):
     import oracle as orc
     name, prime, n, right, iters = case
+    if chunks > 1 and name not in ("rand300x200", "rand3000x2000"):
+        pytest.skip("the chunked layouts are exercised on two matrices only (suite time)")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     parts = [q.get(timeout=300) for _ in range(world)]
