@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Whole solve of a bench workload on one GPU, result verified on the host with the oracle's SpMV (test infrastructure).
-Usage: tools/full_solve.py gl7d19 [--right]"""
+Usage: python tests/full_solve.py gl7d19 [--right]"""
 import json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ is where oracle users live
 sys.path[:0] = [os.path.join(ROOT, "block-lanczos-algorithm-parallelization_amd", "python"), os.path.join(ROOT, "oracle"), ROOT]
 import blz, bench, oracle as orc
 name = sys.argv[1]
