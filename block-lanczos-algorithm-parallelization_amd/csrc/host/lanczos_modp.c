@@ -294,6 +294,8 @@ int main(int argc, char **argv)
 		(long)M.nnz);
 	fprintf(stderr, "  - Read in %.2fs\n", wtime() - t_load);
 
+	if (device < 0 || device + gpus > blz_device_count())
+		errx(1, "GPU %d..%d requested but %d HIP device(s) are visible", device, device + gpus - 1, blz_device_count());
 	if (gpus > 1)
 		CHECK(blz_comm_unique_id(team.uid, sizeof team.uid));
 	team.M = &M;

@@ -160,3 +160,15 @@ def test_verify_mode_runs_the_reference_invariants(tmp_path):
     assert r.returncode == 0, r.stderr
     cli = json.load(open(os.path.join(GOLDEN, "cli.json")))
     assert hashlib.sha256(open(out, "rb").read()).hexdigest() == cli["rand300x200_p65537_n4_left"]["out_sha256"]
+
+
+@pytest.mark.gpu
+def test_gpus_flag_reports_missing_devices_cleanly():
+    """--gpus G drives G contexts from one process; asking for more GPUs than the box has must end with a message and
+    exit code 1, not a hang (each rank's ncclCommInitRank would otherwise wait for the missing one)."""
+    import blz
+    have = blz.device_count()
+    mt = os.path.join(GOLDEN, "rand300x200.mtx")
+    r = subprocess.run([EXE, "--matrix", mt, "--prime", "65537", "--n", "4", "--gpus", str(have + 1)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "GPU" in r.stderr, r.stderr
