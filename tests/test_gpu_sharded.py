@@ -133,3 +133,11 @@ def test_rccl_plumbing_on_one_rank(monkeypatch, chunks):
         assert prof["allreduce"]["launches"] == 6
         want = orc.block_lanczos(Mo, n, p, stop_after=6)
         assert np.array_equal(c.get_block(blz.V), want["v"])
+        # and a whole solve through the two-stream pipeline (events are re-used every iteration)
+        c.profile(False)
+        c.init_v()
+        while not c.iterate(64)[1]:
+            pass
+        full = orc.block_lanczos(Mo, n, p)
+        assert c.iterations == full["iterations"]
+        assert np.array_equal(c.get_block(blz.V), full["v"]) and np.array_equal(c.get_block(blz.TMP), full["tmp"])
