@@ -100,13 +100,14 @@ MODP_DEV void acc_add_acc(Acc &a, u64 olo, u64 ohi)
 }
 
 /*
- * Outlier rows.  A row with more than HEAVY_ROW entries would pin one lane group for the whole launch (real
- * relation matrices do have a few very dense rows).  The group that meets one only records it; after the
- * streaming loop the whole workgroup takes the recorded rows one at a time, every group summing a slice, and the
- * slices are added through LDS.  Rows that do not fit the per-block list are processed in place.
+ * Outlier rows.  A row much longer than the average (more than `heavy` = max(64, 4 x mean) entries) would keep one
+ * lane group busy long after its neighbours have finished -- measured on lognormal row lengths, that imbalance, not
+ * divergence inside a wavefront, is what uneven rows cost (tools/exp_skew.py).  The group that meets such a row only
+ * records it; after the streaming loop the whole workgroup takes the recorded rows one at a time, every group
+ * summing a slice, and the slices are added through LDS.  Rows that do not fit the per-block list are processed in
+ * place.
  */
-#define HEAVY_ROW 512u
-#define HEAVY_MAX 32
+#define HEAVY_MAX 48
 
 struct HeavyList {
 	int cnt;
@@ -153,7 +154,7 @@ template <typename W, int G, int MERS>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
        const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, long long rows, int n, int split_log2,
-       int accum, ModP m, const DevCtl *__restrict__ ctl)
+       int accum, u32 heavy, ModP m, const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
@@ -177,7 +178,7 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 	const int leader = (threadIdx.x & 63) & ~((G << split_log2) - 1);
 	for (long long r = g0; r < rows; r += ng) {
 		u32 k = rp[r], e = rp[r + 1];
-		if (e - k > (HEAVY_ROW << split_log2) && heavy_defer(hl, r, lane, part, leader))
+		if (e - k > (heavy << split_log2) && heavy_defer(hl, r, lane, part, leader))
 			continue;
 		if (split_log2) {
 			const u32 len = e - k, per = (len + (1u << split_log2) - 1u) >> split_log2;
@@ -209,6 +210,12 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 	}
 }
 
+static inline u32 heavy_threshold(const DevCsr &A)
+{
+	const double avg = A.rows ? (double)A.nnz / (double)A.rows : 0.0;
+	return (u32)(4.0 * avg < 64.0 ? 64.0 : 4.0 * avg);
+}
+
 template <typename W, int MERS>
 static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, int accum, const DevCtl *ctl,
 				hipStream_t s)
@@ -238,7 +245,8 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 #define SPMV_CASE(GG)                                                                                             \
 	case GG:                                                                                                  \
 		hipLaunchKernelGGL((k_spmv<W, GG, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr,  \
-				   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, accum, c.m, ctl); \
+				   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, accum,     \
+				   heavy_threshold(A), c.m, ctl);                                                  \
 		break;
 	switch (G) {
 		SPMV_CASE(1)
@@ -456,7 +464,7 @@ template <typename W, int MERS, int NT>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
 	   const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
-	   long long rows, int accum, ModP m, u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
+	   long long rows, int accum, u32 heavy, ModP m, u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
@@ -478,7 +486,7 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 	ds.init();
 	for (long long r = g0; r < rows; r += ng) {
 		const u32 k = rp[r], e = rp[r + 1];
-		if (e - k > HEAVY_ROW && heavy_defer(hl, r, lane, 0u, gbase))
+		if (e - k > heavy && heavy_defer(hl, r, lane, 0u, gbase))
 			continue;
 		const u64 vi = Vd[(size_t)r * NT + lane];
 		Acc acc;
@@ -520,7 +528,7 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 #define SPMV_DOT(NN)                                                                                                \
 	case NN:                                                                                                    \
 		hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
-				   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, c.m, partial, ctl);        \
+				   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, heavy_threshold(A), c.m, partial, ctl); \
 		break;
 	switch (c.n) {
 		SPMV_DOT(1)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Experiment: how much do uneven row lengths cost the group-per-row SpMV, and does grouping rows of similar length help?
+Synthetic 1 M x 1 M matrix, ~20 entries per row on average, lognormal row lengths, uniform columns."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "block-lanczos-algorithm-parallelization_amd", "python"))
+import blz
+P61, n, R, C = (1 << 61) - 1, 8, 1000000, 1000000
+rng = np.random.default_rng(3)
+def build(lengths):
+    i = np.repeat(np.arange(R, dtype=np.int32), lengths)
+    j = rng.integers(0, C, size=i.size, dtype=np.int32)
+    x = rng.integers(1, 4, size=i.size).astype(np.uint32)
+    return blz.Matrix(R, C, i, j, x)
+def timeit(M, tag, env=None):
+    for k, v in (env or {}).items():
+        os.environ[k] = v
+    ctx = blz.Context(P61, n); ctx.set_matrix(M, False); ctx.init_v(); ctx.iterate(2)
+    a, b = ctx.time_kernel(0, 10) * 1e3, ctx.time_kernel(1, 10) * 1e3
+    print(f"{tag:46s} nnz {M.nnz/1e6:5.1f} M  M^T v: {a:7.1f} us ({M.nnz/a/1e3:5.1f} G entries/s)   M tmp: {b:7.1f} us ({M.nnz/b/1e3:5.1f} G entries/s)", flush=True)
+    ctx.close()
+    for k in (env or {}):
+        os.environ.pop(k)
+uniform = np.full(R, 20)
+timeit(build(uniform), "uniform rows of 20")
+for sigma in (0.5, 1.0, 1.5):
+    L = np.clip(rng.lognormal(np.log(20) - sigma * sigma / 2, sigma, R), 1, 20000).astype(np.int64)
+    M = build(L)
+    timeit(M, f"lognormal sigma={sigma} (max {L.max()}, median {int(np.median(L))})")
