@@ -84,6 +84,10 @@ def main():
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
 
+    if world > 1 and "OMP_NUM_THREADS" not in os.environ:
+        # the host-side set-up (generation, renumbering, CSR builds) is OpenMP code: share the cores between the ranks
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))
+
     import numpy as np
     import blz
     blz.lib()       # load libblz_hip.so (and with it /opt/rocm's HIP runtime) before torch brings its own copy
