@@ -173,6 +173,7 @@ static void free_csr(DevCsr &A)
 	if (A.col_idx) hipFree(A.col_idx);
 	if (A.val) hipFree(A.val);
 	if (A.palette) hipFree(A.palette);
+	if (A.heavy_rows) hipFree(A.heavy_rows);
 	A = DevCsr{};
 }
 
@@ -324,7 +325,25 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
 			HIPCHK(hipMemcpy(D.val, H.val, (size_t)H.nnz * sizeof(u32), hipMemcpyHostToDevice));
 		}
 	}
-	(void)c;
+	D.heavy_thr = spmv_heavy_threshold(c->cfg, H.rows, H.nnz);
+	std::vector<int> heavy;
+	double sq = 0.0;
+	for (int64_t r = 0; r < H.rows; r++) {
+		const u32 len = H.row_ptr[r + 1] - H.row_ptr[r];
+		if (len > D.heavy_thr)
+			heavy.push_back((int)r);
+		else
+			sq += (double)len * (double)len;
+	}
+	if (H.rows > 0) {
+		const double mean = (double)H.nnz / (double)H.rows, var = sq / (double)H.rows - mean * mean;
+		D.uneven = var > 0.25 * mean * mean;
+	}
+	D.n_heavy = (int)heavy.size();
+	if (D.n_heavy) {
+		HIPCHK(hipMalloc(&D.heavy_rows, heavy.size() * sizeof(int)));
+		HIPCHK(hipMemcpy(D.heavy_rows, heavy.data(), heavy.size() * sizeof(int), hipMemcpyHostToDevice));
+	}
 	return BLZ_OK;
 }
 

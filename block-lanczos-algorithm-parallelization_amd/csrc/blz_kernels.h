@@ -12,6 +12,10 @@ struct DevCsr {
 	int *col_idx = nullptr;
 	u32 *val = nullptr;	/* nullptr: all ones, or packed (palette != nullptr) */
 	u32 *palette = nullptr;	/* 256 values: col_idx then holds  column | (palette index << 24)  */
+	int *heavy_rows = nullptr;	/* rows longer than heavy_thr, ascending: handled by k_spmv_heavy */
+	int n_heavy = 0;
+	u32 heavy_thr = 0xFFFFFFFFu;
+	bool uneven = false;		/* row lengths vary a lot (std > mean/2): the SpMV wants more resident waves */
 };
 
 /* Control words shared by all kernels of a context (device memory). */
@@ -30,6 +34,9 @@ struct KernelCfg {
 	int num_cu;
 	int spmv_blocks_per_cu;	/* grid of the persistent SpMV = num_cu * this (BLZ_SPMV_BLOCKS_PER_CU overrides) */
 };
+
+/* rows of a slab with more entries than this get a workgroup each (DevCsr::heavy_rows) */
+u32 spmv_heavy_threshold(const KernelCfg &c, int64_t rows, int64_t nnz);
 
 /* Y[rows x n] = A * X, X addressed through A.col_idx (row-major, n words per row).
  * sequential/lanczos_modp.c:266-287 */

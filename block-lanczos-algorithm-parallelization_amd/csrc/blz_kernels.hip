@@ -100,32 +100,14 @@ MODP_DEV void acc_add_acc(Acc &a, u64 olo, u64 ohi)
 }
 
 /*
- * Outlier rows.  A row much longer than the average (more than `heavy` = max(64, 4 x mean) entries) would keep one
- * lane group busy long after its neighbours have finished -- measured on lognormal row lengths, that imbalance, not
- * divergence inside a wavefront, is what uneven rows cost (tools/exp_skew.py).  The group that meets such a row only
- * records it; after the streaming loop the whole workgroup takes the recorded rows one at a time, every group
- * summing a slice, and the slices are added through LDS.  Rows that do not fit the per-block list are processed in
- * place.
+ * Outlier rows.  A row much longer than the average (more than A.heavy_thr = max(64, 4 x mean) entries) would keep
+ * one lane group busy long after its neighbours have finished -- measured on lognormal row lengths, that imbalance,
+ * not divergence inside a wavefront, is what uneven rows cost (tools/exp_skew.py).  Such rows are listed on the host
+ * when the slab is uploaded (DevCsr::heavy_rows); the streaming kernels skip them and a second, small launch
+ * (k_spmv_heavy) gives each of them a whole workgroup: every lane group sums a slice, the slices are added through
+ * LDS.  Being a launch of its own, it spreads the outliers over the chip wherever they sit in the row order (a
+ * renumbering by smallest column puts all dense rows next to each other).
  */
-#define HEAVY_MAX 48
-
-struct HeavyList {
-	int cnt;
-	long long rows[HEAVY_MAX];
-};
-
-/* returns true when row r was put on the list (uniform over all lanes that share the row) */
-MODP_DEV bool heavy_defer(HeavyList &hl, long long r, int lane, u32 part, int leader_lane)
-{
-	int idx = 0;
-	if (lane == 0 && part == 0) {
-		idx = atomicAdd(&hl.cnt, 1);
-		if (idx < HEAVY_MAX)
-			hl.rows[idx] = r;
-	}
-	idx = __shfl(idx, leader_lane, 64);
-	return idx < HEAVY_MAX;
-}
 
 /* all threads of the block: sum row r over BLOCK/G slices; group 0 returns the 128-bit total */
 template <typename W, int G>
@@ -150,6 +132,19 @@ MODP_DEV Acc heavy_row_sum(long long r, const u32 *__restrict__ rp, const int *_
 	return acc;
 }
 
+template <typename W, int G, int MERS, bool DOT>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_heavy(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
+	     const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
+	     const int *__restrict__ hrows, int nh, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
+	     const DevCtl *__restrict__ ctl);
+
+static inline long long heavy_blocks(const KernelCfg &c, const DevCsr &A, long long room)
+{
+	long long b = A.n_heavy < (long long)c.num_cu * 4 ? A.n_heavy : (long long)c.num_cu * 4;
+	return b < room ? b : room;
+}
+
 template <typename W, int G, int MERS>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
@@ -158,14 +153,10 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 {
 	if (ctl->stop)
 		return;
-	__shared__ HeavyList hl;
-	__shared__ Acc slices[BLOCK / G][G];
 	__shared__ u32 spal_store[BLOCK];
 	const u32 *spal = pal ? spal_store : nullptr;
 	if (pal)
 		spal_store[threadIdx.x] = pal[threadIdx.x];
-	if (threadIdx.x == 0)
-		hl.cnt = 0;
 	__syncthreads();
 	const int lane = threadIdx.x & (G - 1);
 	const int xl = lane < n ? lane : 0;
@@ -175,10 +166,9 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 	const long long g0 = gid >> split_log2;
 	const u32 part = (u32)gid & ((1u << split_log2) - 1u);
 	const long long ng = ((long long)gridDim.x * (BLOCK / G)) >> split_log2;
-	const int leader = (threadIdx.x & 63) & ~((G << split_log2) - 1);
 	for (long long r = g0; r < rows; r += ng) {
 		u32 k = rp[r], e = rp[r + 1];
-		if (e - k > (heavy << split_log2) && heavy_defer(hl, r, lane, part, leader))
+		if (e - k > heavy)	/* left to k_spmv_heavy */
 			continue;
 		if (split_log2) {
 			const u32 len = e - k, per = (len + (1u << split_log2) - 1u) >> split_log2;
@@ -197,23 +187,27 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 			Y[(size_t)r * n + lane] = (W)acc_reduce<MERS>(acc, m);
 		}
 	}
-	__syncthreads();
-	const int nh = hl.cnt < HEAVY_MAX ? hl.cnt : HEAVY_MAX;
-	for (int h = 0; h < nh; h++) {
-		const long long r = hl.rows[h];
-		Acc acc = heavy_row_sum<W, G>(r, rp, ci, va, spal, X, n, xl, slices);
-		if (threadIdx.x < G && lane < n) {
-			if (accum)
-				acc_add(acc, Y[(size_t)r * n + lane]);
-			Y[(size_t)r * n + lane] = (W)acc_reduce<MERS>(acc, m);
-		}
-	}
 }
 
-static inline u32 heavy_threshold(const DevCsr &A)
+static int spmv_split_log2(const KernelCfg &c, int64_t rows, int64_t nnz)
 {
-	const double avg = A.rows ? (double)A.nnz / (double)A.rows : 0.0;
-	return (u32)(4.0 * avg < 64.0 ? 64.0 : 4.0 * avg);
+	int G = 1;
+	while (G < c.n)
+		G <<= 1;
+	const long long groups_per_block = BLOCK / G;
+	const double avg = rows ? (double)nnz / (double)rows : 0.0;
+	int split_log2 = 0;
+	while ((G << (split_log2 + 1)) <= 64 && (double)rows * (1 << split_log2) < 2.0 * c.num_cu * 8 * groups_per_block
+	       && avg / (1 << (split_log2 + 1)) >= 4.0)
+		split_log2++;
+	return split_log2;
+}
+
+u32 spmv_heavy_threshold(const KernelCfg &c, int64_t rows, int64_t nnz)
+{
+	const double avg = rows ? (double)nnz / (double)rows : 0.0;
+	const u32 base = (u32)(4.0 * avg < 64.0 ? 64.0 : 4.0 * avg);
+	return base << spmv_split_log2(c, rows, nnz);
 }
 
 template <typename W, int MERS>
@@ -229,15 +223,15 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 	/* measured on MI355X (tools/tune_spmv.py): rows of >= ~12 entries run best with 4 resident blocks per CU,
 	 * short rows want 8; few long rows are split over up to 64/G groups */
 	const double avg = (double)A.nnz / (double)A.rows;
-	int split_log2 = 0;
-	while ((G << (split_log2 + 1)) <= 64 && (double)A.rows * (1 << split_log2) < 2.0 * c.num_cu * 8 * groups_per_block
-	       && avg / (1 << (split_log2 + 1)) >= 4.0)
-		split_log2++;
+	const int split_log2 = spmv_split_log2(c, A.rows, A.nnz);
 	/* (128-byte block rows out of an HBM-sized X are the exception: they want the full 8, measured on the
 	 * config-5 shape) */
 	const bool wide_rows_from_hbm = (size_t)G * sizeof(W) >= 128 && (double)A.cols * c.n * sizeof(W) > 256e6;
+	/* (and so are uneven row lengths: lane groups that have finished their row wait for the longest one of their
+	 * wavefront and issue nothing meanwhile, so more resident wavefronts are needed to keep the fabric busy --
+	 * tools/exp_skew.py, 4 -> 6 blocks per CU: -9 % on lognormal lengths) */
 	int per_cu = c.spmv_blocks_per_cu > 0 ? c.spmv_blocks_per_cu
-					      : ((avg / (1 << split_log2) >= 12.0 && !wide_rows_from_hbm) ? 4 : 8);
+					      : ((avg / (1 << split_log2) >= 12.0 && !wide_rows_from_hbm) ? (A.uneven ? 6 : 4) : 8);
 	long long blocks = ((A.rows << split_log2) + groups_per_block - 1) / groups_per_block;
 	const long long cap = (long long)c.num_cu * per_cu;
 	if (blocks > cap)
@@ -246,7 +240,11 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 	case GG:                                                                                                  \
 		hipLaunchKernelGGL((k_spmv<W, GG, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr,  \
 				   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, accum,     \
-				   heavy_threshold(A), c.m, ctl);                                                  \
+				   A.heavy_thr, c.m, ctl);                                                         \
+		if (A.n_heavy)                                                                                    \
+			hipLaunchKernelGGL((k_spmv_heavy<W, GG, MERS, false>), dim3((unsigned)heavy_blocks(c, A, 1 << 30)), \
+					   dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, A.val, A.palette, X, Y, (const W *)nullptr, \
+					   A.heavy_rows, A.n_heavy, c.n, accum, c.m, (u64 *)nullptr, 0, ctl);            \
 		break;
 	switch (G) {
 		SPMV_CASE(1)
@@ -402,7 +400,7 @@ struct DotState {
 
 	/* wave: sum the 64/NT groups; block: sum the waves through LDS; one partial row per block.
 	 * Must be reached by every thread of the block. */
-	__device__ __forceinline__ void finish(u64 (*red)[SLOTS][NT], u64 *__restrict__ partial, const ModP &m)
+	__device__ __forceinline__ void finish(u64 (*red)[SLOTS][NT], u64 *__restrict__ partial, const ModP &m, int slot)
 	{
 		const int t = threadIdx.x, lane = t & 63, i = t & (NT - 1);
 #pragma unroll
@@ -421,7 +419,7 @@ struct DotState {
 #pragma unroll
 			for (int w = 0; w < WAVES; w++)
 				x = addmod(x, red[w][q][ii], m.p);
-			u64 *out = partial + (size_t)blockIdx.x * 2 * NT * NT;
+			u64 *out = partial + (size_t)slot * 2 * NT * NT;
 			if (q < NT) {
 				out[ii * NT + ((ii + q) & (NT - 1))] = x;
 			} else {
@@ -451,7 +449,7 @@ k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long ro
 	ds.init();
 	for (long long r = g0; r < rows; r += ng)
 		ds.row(V[(size_t)r * NT + i], AV[(size_t)r * NT + i], i, gbase, m);
-	ds.finish(red, partial, m);
+	ds.finish(red, partial, m, (int)blockIdx.x);
 }
 
 /*
@@ -470,14 +468,10 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 		return;
 	using DS = DotState<Acc, MERS, NT>;
 	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
-	__shared__ HeavyList hl;
-	__shared__ Acc slices[BLOCK / NT][NT];
 	__shared__ u32 spal_store[BLOCK];
 	const u32 *spal = pal ? spal_store : nullptr;
 	if (pal)
 		spal_store[threadIdx.x] = pal[threadIdx.x];
-	if (threadIdx.x == 0)
-		hl.cnt = 0;
 	__syncthreads();
 	const int t = threadIdx.x, lane = t & (NT - 1), gbase = (t & 63) - lane;
 	const long long g0 = ((long long)blockIdx.x * BLOCK + t) / NT;
@@ -486,7 +480,7 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 	ds.init();
 	for (long long r = g0; r < rows; r += ng) {
 		const u32 k = rp[r], e = rp[r + 1];
-		if (e - k > heavy && heavy_defer(hl, r, lane, 0u, gbase))
+		if (e - k > heavy)	/* row and its share of the inner products: k_spmv_heavy */
 			continue;
 		const u64 vi = Vd[(size_t)r * NT + lane];
 		Acc acc;
@@ -498,20 +492,48 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 		Y[(size_t)r * NT + lane] = (W)y;
 		ds.row(vi, y, lane, gbase, m);
 	}
+	ds.finish(red, partial, m, (int)blockIdx.x);
+}
+
+/* The outlier rows of a slab, one workgroup per row (see "Outlier rows" above).  DOT: the launch follows k_spmv_dot
+ * and adds these rows' share of v^T Av and Av^T Av as partial rows slot0 + blockIdx.x (n = G). */
+template <typename W, int G, int MERS, bool DOT>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_heavy(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
+	     const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
+	     const int *__restrict__ hrows, int nh, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
+	     const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int NT = DOT ? G : 1;
+	using DS = DotState<Acc, MERS, NT>;
+	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
+	__shared__ Acc slices[BLOCK / G][G];
+	__shared__ u32 spal_store[BLOCK];
+	const u32 *spal = pal ? spal_store : nullptr;
+	if (pal)
+		spal_store[threadIdx.x] = pal[threadIdx.x];
 	__syncthreads();
-	const int nh = hl.cnt < HEAVY_MAX ? hl.cnt : HEAVY_MAX;
-	for (int h = 0; h < nh; h++) {
-		const long long r = hl.rows[h];
-		Acc acc = heavy_row_sum<W, NT>(r, rp, ci, va, spal, X, NT, lane, slices);
-		if (t < NT) {
+	const int lane = threadIdx.x & (G - 1);
+	const int xl = lane < n ? lane : 0;
+	DS ds;
+	if (DOT)
+		ds.init();
+	for (int h = blockIdx.x; h < nh; h += gridDim.x) {
+		const long long r = hrows[h];
+		Acc acc = heavy_row_sum<W, G>(r, rp, ci, va, spal, X, n, xl, slices);
+		if (threadIdx.x < G && lane < n) {
 			if (accum)
-				acc_add(acc, Y[(size_t)r * NT + lane]);
+				acc_add(acc, Y[(size_t)r * n + lane]);
 			const u64 y = acc_reduce<MERS>(acc, m);
-			Y[(size_t)r * NT + lane] = (W)y;
-			ds.row(Vd[(size_t)r * NT + lane], y, lane, gbase, m);
+			Y[(size_t)r * n + lane] = (W)y;
+			if (DOT)
+				ds.row(Vd[(size_t)r * n + lane], y, lane, 0, m);
 		}
 	}
-	ds.finish(red, partial, m);
+	if (DOT)
+		ds.finish(red, partial, m, slot0 + (int)blockIdx.x);
 }
 
 template <typename W, int MERS>
@@ -522,13 +544,19 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 	long long blocks = (A.rows + gpb - 1) / gpb;
 	/* the accumulators cost registers: 4 resident blocks per CU at n = 8 (3 at n = 16), so size the grid for that */
 	const long long per_cu = c.n >= 16 ? 3 : (c.n >= 8 ? 4 : 6);
-	const long long cap = (long long)c.num_cu * per_cu < max_blocks ? (long long)c.num_cu * per_cu : max_blocks;
+	/* partial rows: one per block of the streaming kernel, then one per block of the outlier-row launch */
+	const long long hb = heavy_blocks(c, A, max_blocks / 2);
+	const long long cap = (long long)c.num_cu * per_cu < max_blocks - hb ? (long long)c.num_cu * per_cu : max_blocks - hb;
 	blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
-	*nblocks = (int)blocks;
+	*nblocks = (int)(blocks + hb);
 #define SPMV_DOT(NN)                                                                                                \
 	case NN:                                                                                                    \
 		hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
-				   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, heavy_threshold(A), c.m, partial, ctl); \
+				   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, A.heavy_thr, c.m, partial, ctl); \
+		if (hb)                                                                                             \
+			hipLaunchKernelGGL((k_spmv_heavy<W, NN, MERS, true>), dim3((unsigned)hb), dim3(BLOCK), 0, s, A.row_ptr, \
+					   A.col_idx, A.val, A.palette, X, Y, Vd, A.heavy_rows, A.n_heavy, c.n, accum, c.m, partial, \
+					   (int)blocks, ctl);                                                                \
 		break;
 	switch (c.n) {
 		SPMV_DOT(1)

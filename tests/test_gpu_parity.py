@@ -202,11 +202,7 @@ def test_heavy_rows_do_not_overflow():
         assert np.array_equal(ctx.get_block(blz.TMP), orc.spmv(as_orc(M), vin, True, n, p))
 
 
-@pytest.mark.parametrize("n,p", [(8, P61), (4, 2147483647), (16, 1073741789), (3, P61)])
-def test_outlier_rows_are_handled_by_the_whole_workgroup(n, p):
-    """A few very dense rows and columns among short ones (the shape of real relation matrices): rows above HEAVY_ROW
-    entries are deferred and summed by the whole workgroup; more of them than the per-block list holds (100 adjacent
-    rows of 600) fall back to in-place processing.  Both orientations, through a whole solve."""
+def outlier_matrix(p):
     rng = np.random.default_rng(11)
     nr, nc = 6000, 5000
     ii, jj = [], []
@@ -218,12 +214,37 @@ def test_outlier_rows_are_handled_by_the_whole_workgroup(n, p):
     ii, jj = np.concatenate(ii), np.concatenate(jj)
     jj[::97] = 13                                        # a dense column too (duplicates within a row are legal)
     xx = rng.choice(np.array([1, 2, 3, 2 ** 32 - 1, 2 ** 32 - 2], dtype=np.uint64), size=len(ii)) % p
-    M = blz.Matrix(nr, nc, ii, jj, xx.astype(np.uint32))
+    return blz.Matrix(nr, nc, ii, jj, xx.astype(np.uint32))
+
+
+@pytest.mark.parametrize("n,p", [(8, P61), (4, 2147483647), (16, 1073741789), (3, P61)])
+def test_outlier_rows_get_a_workgroup_each(n, p):
+    """A few very dense rows and columns among short ones (the shape of real relation matrices): rows above
+    max(64, 4 x mean) entries are listed at upload, skipped by the streaming kernels and summed by k_spmv_heavy, one
+    workgroup per row -- including their share of the fused inner products (n = 8, 4, 16) and 100 ADJACENT rows of
+    600, which the renumbering keeps together.  Both orientations, through a whole solve."""
+    M = outlier_matrix(p)
     for right in (False, True):
         want = orc.block_lanczos(as_orc(M), n, p, right=right, stop_after=3)
         got = blz.solve(M, p, n, right=right, stop_after=3, batch=3)
         assert got["iterations"] == 3
         assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
+
+
+@pytest.mark.parametrize("n,p", [(8, P61), (5, 1073741789)])
+def test_outlier_rows_in_column_chunked_products(monkeypatch, n, p):
+    """Same matrix, products cut into 3 column pieces (the multi-GPU pipeline, forced on one rank): a row can be an
+    outlier in one piece and ordinary in the next; every piece accumulates into the same output rows."""
+    monkeypatch.setenv("BLZ_FORCE_COMM", "1")
+    monkeypatch.setenv("BLZ_AG_CHUNKS", "3")
+    M = outlier_matrix(p)
+    want = orc.block_lanczos(as_orc(M), n, p, right=False, stop_after=3)
+    with blz.Context(p, n) as c:
+        c.comm_init(blz.comm_unique_id(), 0, 1)
+        c.set_matrix(M, False, 0, 1)
+        c.init_v()
+        c.iterate(3)
+        assert np.array_equal(c.get_block(blz.V), want["v"]) and np.array_equal(c.get_block(blz.P), want["p"])
 
 
 @pytest.mark.parametrize("name,p,n,right", [("rand3000x2000", P61, 8, False), ("rand300x200", 65537, 4, True),

@@ -28,3 +28,9 @@ for sigma in (0.5, 1.0, 1.5):
     L = np.clip(rng.lognormal(np.log(20) - sigma * sigma / 2, sigma, R), 1, 20000).astype(np.int64)
     M = build(L)
     timeit(M, f"lognormal sigma={sigma} (max {L.max()}, median {int(np.median(L))})")
+    # rows of similar length next to each other (same wavefront), without moving any row far: sort by length
+    # inside windows of W consecutive rows.  BLZ_NO_REORDER=1 so that the order given here is the order used.
+    timeit(M, "  same, file order, no renumbering", {"BLZ_NO_REORDER": "1"})
+    for W in (64, 1024):
+        order = np.concatenate([s + np.argsort(L[s:s + W], kind="stable") for s in range(0, R, W)])
+        timeit(build(L[order]), f"  sorted by length in windows of {W}", {"BLZ_NO_REORDER": "1"})
