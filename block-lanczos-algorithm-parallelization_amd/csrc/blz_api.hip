@@ -173,7 +173,9 @@ static void free_csr(DevCsr &A)
 	if (A.col_idx) hipFree(A.col_idx);
 	if (A.val) hipFree(A.val);
 	if (A.palette) hipFree(A.palette);
-	if (A.heavy_rows) hipFree(A.heavy_rows);
+	if (A.heavy) hipFree(A.heavy);
+	if (A.heavy_multi) hipFree(A.heavy_multi);
+	if (A.heavy_scratch) hipFree(A.heavy_scratch);
 	A = DevCsr{};
 }
 
@@ -326,23 +328,43 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
 		}
 	}
 	D.heavy_thr = spmv_heavy_threshold(c->cfg, H.rows, H.nnz);
-	std::vector<int> heavy;
+	std::vector<HeavySeg> heavy;
+	std::vector<HeavyRow> multi;
 	double sq = 0.0;
 	for (int64_t r = 0; r < H.rows; r++) {
-		const u32 len = H.row_ptr[r + 1] - H.row_ptr[r];
-		if (len > D.heavy_thr)
-			heavy.push_back((int)r);
-		else
+		const u32 k0 = H.row_ptr[r], len = H.row_ptr[r + 1] - k0;
+		if (len <= D.heavy_thr) {
 			sq += (double)len * (double)len;
+			continue;
+		}
+		const u32 cnt = (len + HEAVY_SEG - 1) / HEAVY_SEG, per = (len + cnt - 1) / cnt;
+		if (cnt > 1)
+			multi.push_back(HeavyRow{(int)r, (int)heavy.size(), (int)cnt});
+		for (u32 q = 0; q < cnt; q++)
+			heavy.push_back(HeavySeg{(int)r, k0 + q * per, k0 + std::min(len, (q + 1) * per), cnt == 1});
 	}
-	if (H.rows > 0) {
-		const double mean = (double)H.nnz / (double)H.rows, var = sq / (double)H.rows - mean * mean;
-		D.uneven = var > 0.25 * mean * mean;
+	{	/* spread of the rows the streaming kernel keeps */
+		int64_t lrows = H.rows, lnnz = H.nnz;
+		for (const HeavySeg &sg : heavy) {
+			lnnz -= sg.k1 - sg.k0;
+			if (sg.k0 == H.row_ptr[sg.row])
+				lrows--;
+		}
+		if (lrows > 0) {
+			const double mean = (double)lnnz / (double)lrows, var = sq / (double)lrows - mean * mean;
+			D.uneven = var > 0.25 * mean * mean;
+		}
 	}
 	D.n_heavy = (int)heavy.size();
+	D.n_multi = (int)multi.size();
 	if (D.n_heavy) {
-		HIPCHK(hipMalloc(&D.heavy_rows, heavy.size() * sizeof(int)));
-		HIPCHK(hipMemcpy(D.heavy_rows, heavy.data(), heavy.size() * sizeof(int), hipMemcpyHostToDevice));
+		HIPCHK(hipMalloc(&D.heavy, heavy.size() * sizeof(HeavySeg)));
+		HIPCHK(hipMemcpy(D.heavy, heavy.data(), heavy.size() * sizeof(HeavySeg), hipMemcpyHostToDevice));
+	}
+	if (D.n_multi) {
+		HIPCHK(hipMalloc(&D.heavy_multi, multi.size() * sizeof(HeavyRow)));
+		HIPCHK(hipMemcpy(D.heavy_multi, multi.data(), multi.size() * sizeof(HeavyRow), hipMemcpyHostToDevice));
+		HIPCHK(hipMalloc(&D.heavy_scratch, heavy.size() * 64 * 2 * sizeof(u64)));
 	}
 	return BLZ_OK;
 }

@@ -5,6 +5,17 @@
 #include <hip/hip_runtime.h>
 #include "modp.h"
 
+/* Outlier rows of a slab (more than heavy_thr entries), cut into segments of at most HEAVY_SEG entries. */
+#define HEAVY_SEG 4096u
+struct HeavySeg {
+	int row;
+	u32 k0, k1;		/* entries [k0, k1) of col_idx / val */
+	int whole_row;		/* the row is this one segment: k_spmv_heavy finishes it */
+};
+struct HeavyRow {
+	int row, first, count;	/* a split row: segments [first, first + count) of the list */
+};
+
 /* One CSR slab resident in HBM. */
 struct DevCsr {
 	int64_t rows = 0, cols = 0, nnz = 0;
@@ -12,8 +23,11 @@ struct DevCsr {
 	int *col_idx = nullptr;
 	u32 *val = nullptr;	/* nullptr: all ones, or packed (palette != nullptr) */
 	u32 *palette = nullptr;	/* 256 values: col_idx then holds  column | (palette index << 24)  */
-	int *heavy_rows = nullptr;	/* rows longer than heavy_thr, ascending: handled by k_spmv_heavy */
+	HeavySeg *heavy = nullptr;	/* segments of the rows longer than heavy_thr: handled by k_spmv_heavy */
 	int n_heavy = 0;
+	HeavyRow *heavy_multi = nullptr;	/* the rows among them that span several segments */
+	int n_multi = 0;
+	u64 *heavy_scratch = nullptr;	/* 128-bit partial sums: [segment][G lanes][lo, hi] */
 	u32 heavy_thr = 0xFFFFFFFFu;
 	bool uneven = false;		/* row lengths vary a lot (std > mean/2): the SpMV wants more resident waves */
 };
@@ -35,7 +49,7 @@ struct KernelCfg {
 	int spmv_blocks_per_cu;	/* grid of the persistent SpMV = num_cu * this (BLZ_SPMV_BLOCKS_PER_CU overrides) */
 };
 
-/* rows of a slab with more entries than this get a workgroup each (DevCsr::heavy_rows) */
+/* rows of a slab with more entries than this get a workgroup each (DevCsr::heavy) */
 u32 spmv_heavy_threshold(const KernelCfg &c, int64_t rows, int64_t nnz);
 
 /* Y[rows x n] = A * X, X addressed through A.col_idx (row-major, n words per row).

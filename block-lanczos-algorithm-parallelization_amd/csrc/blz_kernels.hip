@@ -103,21 +103,19 @@ MODP_DEV void acc_add_acc(Acc &a, u64 olo, u64 ohi)
  * Outlier rows.  A row much longer than the average (more than A.heavy_thr = max(64, 4 x mean) entries) would keep
  * one lane group busy long after its neighbours have finished -- measured on lognormal row lengths, that imbalance,
  * not divergence inside a wavefront, is what uneven rows cost (tools/exp_skew.py).  Such rows are listed on the host
- * when the slab is uploaded (DevCsr::heavy_rows); the streaming kernels skip them and a second, small launch
- * (k_spmv_heavy) gives each of them a whole workgroup: every lane group sums a slice, the slices are added through
- * LDS.  Being a launch of its own, it spreads the outliers over the chip wherever they sit in the row order (a
+ * when the slab is uploaded (DevCsr::heavy); the streaming kernels skip them and a second, small launch
+ * (k_spmv_heavy) gives each of them a whole workgroup -- several for a row of more than HEAVY_SEG entries, whose
+ * 128-bit segment sums a third launch adds: every lane group sums a slice, the slices are added through LDS.  Being a launch of its own, it spreads the outliers over the chip wherever they sit in the row order (a
  * renumbering by smallest column puts all dense rows next to each other).
  */
 
-/* all threads of the block: sum row r over BLOCK/G slices; group 0 returns the 128-bit total */
+/* all threads of the block: sum entries [k0, e0) over BLOCK/G slices; group 0 returns the 128-bit total */
 template <typename W, int G>
-MODP_DEV Acc heavy_row_sum(long long r, const u32 *__restrict__ rp, const int *__restrict__ ci,
-			   const u32 *__restrict__ va, const u32 *spal, const W *__restrict__ X, int stride, int xl,
-			   Acc (*slices)[G])
+MODP_DEV Acc heavy_range_sum(u32 k0, u32 e0, const int *__restrict__ ci, const u32 *__restrict__ va, const u32 *spal,
+			     const W *__restrict__ X, int stride, int xl, Acc (*slices)[G])
 {
 	constexpr int GPB = BLOCK / G;
 	const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
-	const u32 k0 = rp[r], e0 = rp[r + 1];
 	const u32 per = (e0 - k0 + GPB - 1) / GPB;
 	const u32 lo = k0 + (u32)grp * per;
 	Acc acc;
@@ -134,15 +132,39 @@ MODP_DEV Acc heavy_row_sum(long long r, const u32 *__restrict__ rp, const int *_
 
 template <typename W, int G, int MERS, bool DOT>
 __global__ void __launch_bounds__(BLOCK)
-k_spmv_heavy(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
-	     const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
-	     const int *__restrict__ hrows, int nh, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
+k_spmv_heavy(const int *__restrict__ ci, const u32 *__restrict__ va, const u32 *__restrict__ pal,
+	     const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd, const HeavySeg *__restrict__ segs,
+	     int nseg, u64 *__restrict__ scratch, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
 	     const DevCtl *__restrict__ ctl);
+template <typename W, int G, int MERS, bool DOT>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_heavy_combine(const HeavyRow *__restrict__ mrows, int nm, const u64 *__restrict__ scratch, W *__restrict__ Y,
+		     const W *__restrict__ Vd, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
+		     const DevCtl *__restrict__ ctl);
 
+/* blocks of the two outlier launches: one per segment (bounded), and one per BLOCK/G split rows */
 static inline long long heavy_blocks(const KernelCfg &c, const DevCsr &A, long long room)
 {
 	long long b = A.n_heavy < (long long)c.num_cu * 4 ? A.n_heavy : (long long)c.num_cu * 4;
 	return b < room ? b : room;
+}
+
+static inline long long combine_blocks(const DevCsr &A, int G)
+{
+	const long long b = ((long long)A.n_multi + BLOCK / G - 1) / (BLOCK / G);
+	return b < 16 ? b : 16;
+}
+
+template <typename W, int G, int MERS, bool DOT>
+static void launch_heavy(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum, u64 *partial,
+			 int slot0, long long hb, const DevCtl *ctl, hipStream_t s)
+{
+	hipLaunchKernelGGL((k_spmv_heavy<W, G, MERS, DOT>), dim3((unsigned)hb), dim3(BLOCK), 0, s, A.col_idx, A.val,
+			   A.palette, X, Y, Vd, A.heavy, A.n_heavy, A.heavy_scratch, c.n, accum, c.m, partial, slot0, ctl);
+	if (A.n_multi)
+		hipLaunchKernelGGL((k_spmv_heavy_combine<W, G, MERS, DOT>), dim3((unsigned)combine_blocks(A, G)), dim3(BLOCK),
+				   0, s, A.heavy_multi, A.n_multi, A.heavy_scratch, Y, Vd, c.n, accum, c.m, partial,
+				   slot0 + (int)hb, ctl);
 }
 
 template <typename W, int G, int MERS>
@@ -242,9 +264,8 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 				   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, accum,     \
 				   A.heavy_thr, c.m, ctl);                                                         \
 		if (A.n_heavy)                                                                                    \
-			hipLaunchKernelGGL((k_spmv_heavy<W, GG, MERS, false>), dim3((unsigned)heavy_blocks(c, A, 1 << 30)), \
-					   dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, A.val, A.palette, X, Y, (const W *)nullptr, \
-					   A.heavy_rows, A.n_heavy, c.n, accum, c.m, (u64 *)nullptr, 0, ctl);            \
+			launch_heavy<W, GG, MERS, false>(c, A, X, Y, (const W *)nullptr, accum, (u64 *)nullptr, 0,   \
+							 heavy_blocks(c, A, 1 << 30), ctl, s);                        \
 		break;
 	switch (G) {
 		SPMV_CASE(1)
@@ -495,13 +516,15 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 	ds.finish(red, partial, m, (int)blockIdx.x);
 }
 
-/* The outlier rows of a slab, one workgroup per row (see "Outlier rows" above).  DOT: the launch follows k_spmv_dot
- * and adds these rows' share of v^T Av and Av^T Av as partial rows slot0 + blockIdx.x (n = G). */
+/* The outlier rows of a slab (see "Outlier rows" above), one workgroup per segment of at most HEAVY_SEG entries.
+ * A row that is one segment is finished here; the 128-bit sums of a split row go to `scratch` and
+ * k_spmv_heavy_combine adds them.  DOT: the launches follow k_spmv_dot and add these rows' share of v^T Av and
+ * Av^T Av as partial rows slot0 + blockIdx.x (n = G). */
 template <typename W, int G, int MERS, bool DOT>
 __global__ void __launch_bounds__(BLOCK)
-k_spmv_heavy(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
-	     const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
-	     const int *__restrict__ hrows, int nh, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
+k_spmv_heavy(const int *__restrict__ ci, const u32 *__restrict__ va, const u32 *__restrict__ pal,
+	     const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd, const HeavySeg *__restrict__ segs,
+	     int nseg, u64 *__restrict__ scratch, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
 	     const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
@@ -520,16 +543,59 @@ k_spmv_heavy(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *
 	DS ds;
 	if (DOT)
 		ds.init();
-	for (int h = blockIdx.x; h < nh; h += gridDim.x) {
-		const long long r = hrows[h];
-		Acc acc = heavy_row_sum<W, G>(r, rp, ci, va, spal, X, n, xl, slices);
+	for (int h = blockIdx.x; h < nseg; h += gridDim.x) {
+		const HeavySeg sg = segs[h];
+		Acc acc = heavy_range_sum<W, G>(sg.k0, sg.k1, ci, va, spal, X, n, xl, slices);
 		if (threadIdx.x < G && lane < n) {
+			if (!sg.whole_row) {
+				scratch[((size_t)h * G + lane) * 2] = acc.lo;
+				scratch[((size_t)h * G + lane) * 2 + 1] = acc.hi;
+				continue;
+			}
+			const long long r = sg.row;
 			if (accum)
 				acc_add(acc, Y[(size_t)r * n + lane]);
 			const u64 y = acc_reduce<MERS>(acc, m);
 			Y[(size_t)r * n + lane] = (W)y;
 			if (DOT)
 				ds.row(Vd[(size_t)r * n + lane], y, lane, 0, m);
+		}
+	}
+	if (DOT)
+		ds.finish(red, partial, m, slot0 + (int)blockIdx.x);
+}
+
+/* one lane group per split row: add its segments' sums, reduce, store (and feed the inner products) */
+template <typename W, int G, int MERS, bool DOT>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_heavy_combine(const HeavyRow *__restrict__ mrows, int nm, const u64 *__restrict__ scratch, W *__restrict__ Y,
+		     const W *__restrict__ Vd, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
+		     const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int NT = DOT ? G : 1;
+	using DS = DotState<Acc, MERS, NT>;
+	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
+	const int lane = threadIdx.x & (G - 1), gbase = (threadIdx.x & 63) - lane;
+	const int g0 = (blockIdx.x * BLOCK + threadIdx.x) / G, ng = gridDim.x * (BLOCK / G);
+	DS ds;
+	if (DOT)
+		ds.init();
+	for (int q = g0; q < nm; q += ng) {
+		const HeavyRow hr = mrows[q];
+		Acc acc;
+		acc_zero(acc);
+		if (lane < n) {
+			for (int sidx = hr.first; sidx < hr.first + hr.count; sidx++)
+				acc_add_acc(acc, scratch[((size_t)sidx * G + lane) * 2], scratch[((size_t)sidx * G + lane) * 2 + 1]);
+			const long long r = hr.row;
+			if (accum)
+				acc_add(acc, Y[(size_t)r * n + lane]);
+			const u64 y = acc_reduce<MERS>(acc, m);
+			Y[(size_t)r * n + lane] = (W)y;
+			if (DOT)
+				ds.row(Vd[(size_t)r * n + lane], y, lane, gbase, m);
 		}
 	}
 	if (DOT)
@@ -545,18 +611,17 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 	/* the accumulators cost registers: 4 resident blocks per CU at n = 8 (3 at n = 16), so size the grid for that */
 	const long long per_cu = c.n >= 16 ? 3 : (c.n >= 8 ? 4 : 6);
 	/* partial rows: one per block of the streaming kernel, then one per block of the outlier-row launch */
-	const long long hb = heavy_blocks(c, A, max_blocks / 2);
-	const long long cap = (long long)c.num_cu * per_cu < max_blocks - hb ? (long long)c.num_cu * per_cu : max_blocks - hb;
+	const long long hb = heavy_blocks(c, A, max_blocks / 2), cb = A.n_multi ? combine_blocks(A, c.n) : 0;
+	const long long room = max_blocks - hb - cb;
+	const long long cap = (long long)c.num_cu * per_cu < room ? (long long)c.num_cu * per_cu : room;
 	blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
-	*nblocks = (int)(blocks + hb);
+	*nblocks = (int)(blocks + hb + cb);
 #define SPMV_DOT(NN)                                                                                                \
 	case NN:                                                                                                    \
 		hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
 				   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, A.heavy_thr, c.m, partial, ctl); \
 		if (hb)                                                                                             \
-			hipLaunchKernelGGL((k_spmv_heavy<W, NN, MERS, true>), dim3((unsigned)hb), dim3(BLOCK), 0, s, A.row_ptr, \
-					   A.col_idx, A.val, A.palette, X, Y, Vd, A.heavy_rows, A.n_heavy, c.n, accum, c.m, partial, \
-					   (int)blocks, ctl);                                                                \
+			launch_heavy<W, NN, MERS, true>(c, A, X, Y, Vd, accum, partial, (int)blocks, hb, ctl, s);      \
 		break;
 	switch (c.n) {
 		SPMV_DOT(1)

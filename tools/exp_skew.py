@@ -34,3 +34,7 @@ for sigma in (0.5, 1.0, 1.5):
     for W in (64, 1024):
         order = np.concatenate([s + np.argsort(L[s:s + W], kind="stable") for s in range(0, R, W)])
         timeit(build(L[order]), f"  sorted by length in windows of {W}", {"BLZ_NO_REORDER": "1"})
+# relation-matrix style: a handful of very dense rows among constant ones (k_spmv_heavy: one workgroup per 4096 entries)
+for dense_rows, dense_len in ((20, 200000), (2, 1000000)):
+    L = np.full(R, 20); L[rng.choice(R, dense_rows, replace=False)] = dense_len
+    timeit(build(L), f"rows of 20 + {dense_rows} rows of {dense_len}")
