@@ -284,6 +284,7 @@ static void team_get(int block, uint64_t *host)
 int main(int argc, char **argv)
 {
 	process_command_line_options(argc, argv);
+	setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);	/* dmabuf IPC for RCCL; must precede the first HIP call */
 
 	printf("Loading matrix from %s\n", matrix_filename);
 	fflush(stdout);

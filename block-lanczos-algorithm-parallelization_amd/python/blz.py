@@ -44,6 +44,8 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not built (run __graft_entry__.build() or make in {PKG})")
+        # the pool's host driver only supports dmabuf IPC; RCCL across processes needs this before HIP initialises
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         L.blz_last_error.restype = C.c_char_p
         L.blz_rng_next.restype = C.c_uint64
