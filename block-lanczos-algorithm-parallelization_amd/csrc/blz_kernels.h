@@ -57,7 +57,7 @@ u32 spmv_heavy_threshold(const KernelCfg &c, int64_t rows, int64_t nnz);
 hipError_t launch_spmv(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, int accum, const DevCtl *ctl,
 		       hipStream_t s);	/* accum != 0: Y = (Y + A*X) mod p (one piece of a column-chunked product) */
 
-/* Y = A*X with block_dot_products(V_slab, Y) as the epilogue (n in {1,2,4,8,16} only): one partial row per block. */
+/* Y = A*X with block_dot_products(V_slab, Y) as the epilogue (n in {1,2,4,8} only): one partial row per block. */
 bool spmv_dot_supported(const KernelCfg &c);
 hipError_t launch_spmv_dot(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const void *Vd, int accum,
 			   u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s);

@@ -468,8 +468,19 @@ k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long ro
 	const long long g0 = (long long)blockIdx.x * GPB + t / NT, ng = (long long)gridDim.x * GPB;
 	DS ds;
 	ds.init();
-	for (long long r = g0; r < rows; r += ng)
-		ds.row(V[(size_t)r * NT + i], AV[(size_t)r * NT + i], i, gbase, m);
+	W nv = 0, na = 0;		/* next row's operands are in flight during this row's MACs */
+	if (g0 < rows) {
+		nv = V[(size_t)g0 * NT + i];
+		na = AV[(size_t)g0 * NT + i];
+	}
+	for (long long r = g0; r < rows; r += ng) {
+		const u64 vv = nv, aa = na;
+		if (r + ng < rows) {
+			nv = V[(size_t)(r + ng) * NT + i];
+			na = AV[(size_t)(r + ng) * NT + i];
+		}
+		ds.row(vv, aa, i, gbase, m);
+	}
 	ds.finish(red, partial, m, (int)blockIdx.x);
 }
 
@@ -477,7 +488,9 @@ k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long ro
  * Second SpMV of an iteration (Av = M tmp, sequential/lanczos_modp.c:636) with block_dot_products (:640) as its
  * epilogue: the lane that has just produced Av[r,i] loads v[r,i] and feeds both products.  The SpMV is bound by
  * the gather request rate and leaves the VALU idle ~90 % of the time, so the n x n work is free here and the
- * separate pass over v and Av (2*N*n*w bytes) disappears.  n = NT = G in {1,2,4,8,16}.
+ * separate pass over v and Av (2*N*n*w bytes) disappears.  n = NT = G in {1,2,4,8}: at n = 16 the 25 accumulators
+ * per lane cost more occupancy than the saved pass is worth (measured: 15.8 ms fused against 12.4 + 2.3 ms apart on
+ * the config-5 shape), so that width runs k_spmv and k_block_dot_fast.
  */
 template <typename W, int MERS, int NT>
 __global__ void __launch_bounds__(BLOCK)
@@ -608,8 +621,8 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 {
 	const long long gpb = BLOCK / c.n;
 	long long blocks = (A.rows + gpb - 1) / gpb;
-	/* the accumulators cost registers: 4 resident blocks per CU at n = 8 (3 at n = 16), so size the grid for that */
-	const long long per_cu = c.n >= 16 ? 3 : (c.n >= 8 ? 4 : 6);
+	/* the accumulators cost registers: 4 resident blocks per CU at n = 8, so size the grid for that */
+	const long long per_cu = c.n >= 8 ? 4 : 6;
 	/* partial rows: one per block of the streaming kernel, then one per block of the outlier-row launch */
 	const long long hb = heavy_blocks(c, A, max_blocks / 2), cb = A.n_multi ? combine_blocks(A, c.n) : 0;
 	const long long room = max_blocks - hb - cb;
@@ -628,7 +641,6 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 		SPMV_DOT(2)
 		SPMV_DOT(4)
 		SPMV_DOT(8)
-		SPMV_DOT(16)
 	default:
 		return hipErrorInvalidValue;
 	}
@@ -638,7 +650,7 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 
 bool spmv_dot_supported(const KernelCfg &c)
 {
-	return c.n == 1 || c.n == 2 || c.n == 4 || c.n == 8 || c.n == 16;
+	return c.n == 1 || c.n == 2 || c.n == 4 || c.n == 8;
 }
 
 hipError_t launch_spmv_dot(const KernelCfg &c, const DevCsr &A, const void *X, void *Y, const void *Vd, int accum,
