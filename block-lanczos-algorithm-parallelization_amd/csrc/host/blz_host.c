@@ -8,6 +8,7 @@
 
 #include <ctype.h>
 #include <errno.h>
+#include <omp.h>
 #include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -77,6 +78,93 @@ static inline int next_int(cursor *c, long long *out)
 	*out = neg ? -(long long)acc : (long long)acc;
 	c->p = p;
 	return 0;
+}
+
+static inline int is_blank(char ch)
+{
+	return ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f';
+}
+
+/* The entries of a large file, read by all cores: the text is cut into one piece per thread at token boundaries,
+ * pass 1 counts the whitespace-separated tokens of each piece, pass 2 parses token g as field g % 3 of entry g / 3
+ * (any layout fscanf("%d %d %d") accepts, not only one entry per line).  Returns 0 when every one of the 3*nz
+ * tokens was a plain in-range integer; anything else returns 1 WITHOUT an error message and the caller re-reads
+ * the file with the sequential reader, which defines the behaviour on irregular input. */
+static int parse_entries_parallel(const char *p, const char *end, long long nr, long long nc, long long nz,
+				  uint64_t prime, blz_coo *out)
+{
+	int T = omp_get_max_threads();
+	if (T > 64)
+		T = 64;
+	const char *cut[65];
+	long long first[65];
+	cut[0] = p;
+	cut[T] = end;
+	for (int t = 1; t < T; t++) {
+		const char *q = p + (size_t)(end - p) / (size_t)T * (size_t)t;
+		while (q < end && !is_blank(*q))	/* finish the token the cut fell into */
+			q++;
+		cut[t] = q < cut[t - 1] ? cut[t - 1] : q;
+	}
+	int irregular = 0;
+	first[0] = 0;
+#pragma omp parallel for schedule(static, 1)
+	for (int t = 0; t < T; t++) {
+		long long cnt = 0;
+		int in_tok = 0;
+		for (const char *q = cut[t]; q < cut[t + 1]; q++) {
+			const int bl = is_blank(*q);
+			cnt += (!bl && !in_tok);
+			in_tok = !bl;
+		}
+		first[t + 1] = cnt;
+	}
+	for (int k = 1; k <= T; k++)
+		first[k] += first[k - 1];
+	if (first[T] < 3 * nz)
+		return 1;
+#pragma omp parallel for schedule(static, 1) reduction(| : irregular)
+	for (int t = 0; t < T; t++) {
+		long long g = first[t];
+		int bad = 0;
+		const char *q = cut[t], *stop = cut[t + 1];
+		while (!bad && g < 3 * nz) {
+			while (q < stop && is_blank(*q))
+				q++;
+			if (q >= stop)
+				break;
+			int neg = 0;
+			if (*q == '-' || *q == '+')
+				neg = (*q++ == '-');
+			if (q >= stop || *q < '0' || *q > '9') {
+				bad = 1;
+				break;
+			}
+			unsigned long long acc = 0;
+			while (q < stop && *q >= '0' && *q <= '9')
+				acc = acc * 10 + (unsigned)(*q++ - '0');
+			if (q < stop && !is_blank(*q)) {
+				bad = 1;
+				break;
+			}
+			const long long val = neg ? -(long long)acc : (long long)acc, u = g / 3;
+			switch (g % 3) {
+			case 0:
+				bad = val < 1 || val > nr;
+				out->i[u] = (int32_t)(val - 1);
+				break;
+			case 1:
+				bad = val < 1 || val > nc;
+				out->j[u] = (int32_t)(val - 1);
+				break;
+			default:	/* sequential/lanczos_modp.c:238-243: "%d" into a u32, then % prime */
+				out->x[u] = (uint32_t)((uint64_t)(uint32_t)(int32_t)val % prime);
+			}
+			g++;
+		}
+		irregular |= bad;
+	}
+	return irregular;
 }
 
 static void lowercase(char *s)
@@ -166,6 +254,12 @@ int blz_mm_load(const char *path, uint64_t prime, blz_coo *out)
 		blz_coo_free(out);
 		return blz_fail(BLZ_ENOMEM, "Cannot allocate sparse matrix");
 	}
+	if (nz >= 200000 && parse_entries_parallel(c.p, c.end, nr, nc, nz, prime, out) == 0) {
+		munmap(base, (size_t)st.st_size);
+		return BLZ_OK;
+	}
+	/* small file, or something the fast path does not take (a malformed or out-of-range entry, tokens glued
+	 * together): the one-token-at-a-time reader below is the definition, and it names the offending entry */
 	for (long long u = 0; u < nz; u++) {
 		long long a, b, v;
 		if (next_int(&c, &a) || next_int(&c, &b) || next_int(&c, &v)) {

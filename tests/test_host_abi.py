@@ -79,6 +79,53 @@ def test_loader_rejects_what_reference_rejects(tmp_path):
     assert blz.Matrix.load(str(bad), 7).nnz == 0
 
 
+def test_large_files_are_parsed_by_all_cores_with_the_same_result(tmp_path):
+    """Files of >= 200 000 entries take the multi-threaded reader (blz_mm_load): pieces cut at token boundaries, token
+    g = field g % 3 of entry g / 3.  Same triplets as the generator wrote, for the regular layout and for layouts only
+    fscanf-style reading accepts (several entries per line, blank lines, entries split over lines, signs); anything
+    irregular falls back to the sequential reader, which names the offending entry as before."""
+    p = 1073741789
+    M = blz.Matrix.synth(30000, 20000, 250000, 77, p)
+    path = str(tmp_path / "big.mtx")
+    M.save(path)
+    L = blz.Matrix.load(path, p)
+    assert (L.nrows, L.ncols, L.nnz) == (30000, 20000, 250000)
+    assert np.array_equal(L.i, M.i) and np.array_equal(L.j, M.j) and np.array_equal(L.x, M.x)
+    # free-form layout with negative values: -3 is read by "%d" into a u32, then reduced (sequential/...:238-243)
+    rng = np.random.default_rng(5)
+    toks = []
+    for k in range(M.nnz):
+        toks += [str(M.i[k] + 1), str(M.j[k] + 1), "-3" if k % 5 == 0 else "+%d" % M.x[k] if k % 7 == 0 else str(M.x[k])]
+    seps = rng.choice(np.array([" ", "\n", "\t", "  \n\n", "\r\n"]), size=len(toks))
+    odd = str(tmp_path / "odd.mtx")
+    with open(odd, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate integer general\n% free-form\n30000 20000 250000\n")
+        f.write("".join(t + s_ for t, s_ in zip(toks, seps)))
+        f.write("\n17 18 19 trailing tokens are never read\n")
+    O = blz.Matrix.load(odd, p)
+    want_x = M.x.copy()
+    want_x[::5] = (2 ** 32 - 3) % p
+    assert np.array_equal(O.i, M.i) and np.array_equal(O.j, M.j) and np.array_equal(O.x, want_x)
+    # irregular input: same diagnostics as the small-file path
+    text = open(path).read().split("\n")
+    broken = list(text)
+    broken[2 + 123456] = "12 x7 1"
+    open(odd, "w").write("\n".join(broken))
+    with pytest.raises(blz.BlzError) as e:
+        blz.Matrix.load(odd, p)
+    assert e.value.code == blz.EIO and "parse error entry 123456" in str(e.value)
+    broken = list(text)
+    broken[2 + 200001] = "30001 5 1"
+    open(odd, "w").write("\n".join(broken))
+    with pytest.raises(blz.BlzError) as e:
+        blz.Matrix.load(odd, p)
+    assert "entry 200001" in str(e.value) and "outside" in str(e.value)
+    open(odd, "w").write("\n".join(text[:2 + 249000]) + "\n")        # truncated file
+    with pytest.raises(blz.BlzError) as e:
+        blz.Matrix.load(odd, p)
+    assert "parse error entry 249000" in str(e.value)
+
+
 @pytest.mark.parametrize("name", ["rand300x200", "quirks40x30", "wide120x260"])
 def test_csr_is_the_same_matrix(name):
     p = 1073741789
