@@ -681,27 +681,80 @@ int blz_rng_fill(uint64_t *v, int64_t words, uint64_t prime)
 
 /* ---------------------------------------------------------------------- result writer */
 
+/* one line of the kernel file: the reference's "%d" of a u32 (negative from 2^31 on) below 2^32, plain decimal above */
+static inline size_t format_word(char *dst, uint64_t w)
+{
+	char tmp[24];
+	size_t len = 0, k = 0;
+	if (w < 0x100000000ull && (w & 0x80000000ull)) {
+		dst[len++] = '-';
+		w = 0x100000000ull - w;
+	}
+	do {
+		tmp[k++] = (char)('0' + w % 10);
+		w /= 10;
+	} while (w);
+	while (k)
+		dst[len++] = tmp[--k];
+	dst[len++] = '\n';
+	return len;
+}
+
+/* save_vector_block(), sequential/lanczos_modp.c:673-686: column-major, one word per line.  The N*n lines are
+ * formatted by all cores, a few million at a time, and written in order. */
 int blz_save_block(const char *path, int64_t nrows, int n, const uint64_t *v)
 {
+	if (!path || nrows < 0 || n < 1 || (!v && nrows > 0))
+		return blz_fail(BLZ_EINVAL, "blz_save_block: bad argument");
 	FILE *f = fopen(path, "w");
 	if (!f)
 		return blz_fail(BLZ_EIO, "cannot open %s: %s", path, strerror(errno));
-	static char iobuf[1 << 20];
-	setvbuf(f, iobuf, _IOFBF, sizeof iobuf);
 	fprintf(f, "%%%%MatrixMarket matrix array integer general\n");
 	fprintf(f, "%%block of left-kernel vector computed by lanczos_modp\n");
 	fprintf(f, "%ld %d\n", (long)nrows, n);
-	for (int col = 0; col < n; col++)
-		for (int64_t r = 0; r < nrows; r++) {
-			const uint64_t w = v[r * n + col];
-			if (w < 0x100000000ull)
-				fprintf(f, "%d\n", (int)(uint32_t)w);	/* the reference's "%d" of a u32 */
-			else
-				fprintf(f, "%llu\n", (unsigned long long)w);
+	enum { LINE_MAX_BYTES = 21, BATCH = 1 << 22 };
+	const int64_t lines = nrows * n;
+	int T = omp_get_max_threads();
+	if (T > 64)
+		T = 64;
+	if (lines < 100000)
+		T = 1;
+	const int64_t batch = lines < BATCH ? (lines ? lines : 1) : BATCH;
+	const int64_t per = (batch + T - 1) / T;
+	char *buf = malloc((size_t)per * T * LINE_MAX_BYTES);
+	if (!buf) {
+		fclose(f);
+		return blz_fail(BLZ_ENOMEM, "blz_save_block: out of memory");
+	}
+	int rc = BLZ_OK;
+	for (int64_t l0 = 0; l0 < lines && rc == BLZ_OK; l0 += batch) {
+		const int64_t l1 = l0 + batch < lines ? l0 + batch : lines;
+		size_t used[64];
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+		for (int t = 0; t < T; t++) {
+			const int64_t a = l0 + (int64_t)t * per, b = a + per < l1 ? a + per : l1;
+			char *dst = buf + (size_t)t * per * LINE_MAX_BYTES;
+			size_t len = 0;
+			if (a < b) {
+				int64_t col = a / nrows, r = a % nrows;
+				for (int64_t l = a; l < b; l++) {
+					len += format_word(dst + len, v[r * n + col]);
+					if (++r == nrows) {
+						r = 0;
+						col++;
+					}
+				}
+			}
+			used[t] = len;
 		}
-	if (fclose(f))
-		return blz_fail(BLZ_EIO, "write error on %s", path);
-	return BLZ_OK;
+		for (int t = 0; t < T; t++)
+			if (used[t] && fwrite(buf + (size_t)t * per * LINE_MAX_BYTES, 1, used[t], f) != used[t])
+				rc = blz_fail(BLZ_EIO, "write error on %s", path);
+	}
+	free(buf);
+	if (fclose(f) && rc == BLZ_OK)
+		rc = blz_fail(BLZ_EIO, "write error on %s", path);
+	return rc;
 }
 
 /* ------------------------------------------------------------------------ kernel checker */
