@@ -222,6 +222,11 @@ def main():
             "traffic_source": traffic_src,
             "alg_bytes_per_launch": alg_bytes,
             "ms_per_launch": t_spmv_ms,
+            # what this kernel is actually limited by: one fabric request per entry; the
+            # micro-benchmarked ceiling for random block-row gathers on MI355X is 54.7 G requests/s whatever the row
+            # size (profiles/r01_ubench_alu_and_gather.txt)
+            "gathers_per_s": nnz1 / (t_spmv_ms * 1e-3) if t_spmv_ms else None,
+            "gather_ceiling_per_s": 54.7e9,
         },
         "device_ms_per_step": dev_ms / args.steps,
         "kernels": kernels,
