@@ -124,6 +124,8 @@ struct blz_ctx {
 	bool reorder = true;		/* BLZ_NO_REORDER=1 keeps the file's numbering */
 	bool pack = true;		/* BLZ_NO_PACK=1 keeps col_idx and val as two arrays */
 	bool fuse_dot = true;		/* BLZ_NO_FUSE=1 keeps block_dot as its own kernel (A/B measurements) */
+	bool use_graph = false;		/* BLZ_GRAPH=1: single-GPU iterations are replayed from a captured hipGraph */
+	hipGraphExec_t iter_graph = nullptr;
 	bool external_exchange = false;
 	bool force_comm = false;	/* BLZ_FORCE_COMM=1: issue the collectives even on one rank (plumbing test) */
 };
@@ -223,6 +225,8 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	c->reorder = !(nr && nr[0] == '1');
 	const char *nf = getenv("BLZ_NO_FUSE");
 	c->fuse_dot = !(nf && nf[0] == '1');
+	const char *ug = getenv("BLZ_GRAPH");
+	c->use_graph = ug && ug[0] == '1';
 	if (const char *ac = getenv("BLZ_AG_CHUNKS"))
 		if (atoi(ac) >= 1 && atoi(ac) <= 64)
 			c->ag_chunks = atoi(ac);
@@ -256,6 +260,8 @@ extern "C" void blz_destroy(blz_ctx *c)
 	}
 	for (auto &e : c->pool)
 		hipEventDestroy(e);
+	if (c->iter_graph)
+		hipGraphExecDestroy(c->iter_graph);
 	if (c->comm && g_rccl.CommDestroy)
 		g_rccl.CommDestroy(c->comm);
 	for (int t = 0; t < 2; t++)
@@ -378,6 +384,10 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 	if (nranks > 1 && (unsigned __int128)nranks * c->prime > ((unsigned __int128)1 << 64))
 		return blz_fail(BLZ_EINVAL, "nranks * p must not exceed 2**64 (u64 all-reduce of residues)");
 	HIPCHK(hipSetDevice(c->device));
+	if (c->iter_graph) {
+		hipGraphExecDestroy(c->iter_graph);
+		c->iter_graph = nullptr;
+	}
 	c->right = right ? 1 : 0;
 	c->rank = rank;
 	c->nranks = nranks;
@@ -914,7 +924,25 @@ extern "C" int blz_iterate(blz_ctx *c, int max_iters, int *done, int *stopped, f
 		return blz_fail(BLZ_EINVAL, "blz_iterate: the context is in external-exchange mode");
 	const long long before = c->host_ctl.iterations;
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	const bool graph = c->use_graph && c->nranks == 1 && !c->force_comm && !c->profiling && max_iters > 1;
+	if (graph && !c->iter_graph) {
+		/* the loop body is a fixed sequence of launches with fixed arguments (all state lives in device memory):
+		 * record it once, replay it per iteration */
+		hipGraph_t g = nullptr;
+		HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+		int rc = enqueue_iteration(c);
+		hipError_t e = hipStreamEndCapture(c->stream, &g);
+		if (rc != BLZ_OK)
+			return rc;
+		HIPCHK(e);
+		HIPCHK(hipGraphInstantiate(&c->iter_graph, g, nullptr, nullptr, 0));
+		hipGraphDestroy(g);
+	}
 	for (int it = 0; it < max_iters; it++) {
+		if (graph) {
+			HIPCHK(hipGraphLaunch(c->iter_graph, c->stream));
+			continue;
+		}
 		int rc = enqueue_iteration(c);
 		if (rc != BLZ_OK)
 			return rc;

@@ -286,6 +286,26 @@ def test_packed_and_plain_matrix_streams_agree(monkeypatch, distinct):
         assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
 
 
+def test_graph_replay_gives_the_same_trajectory(monkeypatch):
+    """BLZ_GRAPH=1: the loop body is captured once into a hipGraph and replayed (all state lives in device memory, so
+    the launches have fixed arguments).  Off by default -- measured slower than plain stream launches on ROCm 7.2,
+    DESIGN.md section 5 -- but it must give the same words, including the no-op iterations after termination."""
+    monkeypatch.setenv("BLZ_GRAPH", "1")
+    M, Mo = load_both("rand300x200", 65537)
+    want = orc.block_lanczos(Mo, 4, 65537, right=False)
+    with blz.Context(65537, 4) as ctx:
+        ctx.set_matrix(M, False)
+        ctx.init_v()
+        done, stopped, _ = ctx.iterate(want["iterations"] + 7)
+        assert stopped and done == want["iterations"]
+        assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
+        ctx.set_matrix(M, True)                       # a new matrix drops the recorded graph
+        ctx.init_v()
+        want_r = orc.block_lanczos(Mo, 4, 65537, right=True, stop_after=5)
+        ctx.iterate(5)
+        assert np.array_equal(ctx.get_block(blz.V), want_r["v"])
+
+
 def test_abi_misuse_is_reported_not_crashed():
     with blz.Context(P61, 4) as ctx:
         for call in (lambda: ctx.init_v(), lambda: ctx.iterate(1), lambda: ctx.spmv(False, blz.V, blz.TMP),
