@@ -1,0 +1,160 @@
+/* Host half of libblz_hip.so under AddressSanitizer + UBSan (CPU build; the GPU pool has no sanitizer runs).
+ * Compiled and run by tests/test_host_sanitize.py:  host_sanitize <golden dir> <scratch dir>
+ * Walks every host-side entry point of include/blz.h on small and on multi-threaded-path-sized inputs, including the
+ * error paths; any invalid access aborts the process with a sanitizer report. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "blz.h"
+
+#define REQUIRE(cond)                                                                         \
+	do {                                                                                  \
+		if (!(cond)) {                                                                \
+			fprintf(stderr, "%s:%d: %s failed (%s)\n", __FILE__, __LINE__, #cond, blz_last_error()); \
+			exit(2);                                                              \
+		}                                                                             \
+	} while (0)
+
+static void matrix_round(const blz_coo *M, uint64_t prime, const char *scratch)
+{
+	for (int t = 0; t < 2; t++)
+		for (int pattern = 0; pattern < 2; pattern++) {
+			blz_csr A;
+			REQUIRE(blz_csr_from_coo(M, t, pattern, &A) == BLZ_OK);
+			REQUIRE(A.nnz == M->nnz && A.row_ptr[A.rows] == (uint32_t)M->nnz);
+			int64_t bounds[9];
+			for (int parts = 1; parts <= 8; parts += 3) {
+				REQUIRE(blz_partition_rows(&A, parts, bounds) == BLZ_OK);
+				REQUIRE(bounds[0] == 0 && bounds[parts] == A.rows);
+			}
+			blz_csr_free(&A);
+		}
+	int32_t *rp = malloc(sizeof *rp * (size_t)(M->nrows + 1)), *cp = malloc(sizeof *cp * (size_t)(M->ncols + 1));
+	REQUIRE(rp && cp);
+	REQUIRE(blz_reorder(M, rp, cp) == BLZ_OK);
+	free(rp);
+	free(cp);
+	for (int right = 0; right < 2; right++)
+		for (int nranks = 1; nranks <= 5; nranks += 2)
+			for (int chunks = 1; chunks <= 4; chunks += 3)
+				for (int rank = 0; rank < nranks; rank++) {
+					blz_csr slabs[2];
+					int64_t b0[6], b1[6], stride[2];
+					REQUIRE(blz_shard_matrix(M, right, rank, nranks, chunks, slabs, b0, b1, stride) == BLZ_OK);
+					REQUIRE(stride[0] % chunks == 0 && stride[1] % chunks == 0);
+					for (int s = 0; s < 2; s++) {
+						/* rows of M gather from tmp's side for a left kernel, from v's side for a right one */
+						const int64_t width = stride[s == 0 ? (right ? 0 : 1) : (right ? 1 : 0)] * nranks;
+						for (int64_t k = 0; k < slabs[s].nnz; k++)
+							REQUIRE(slabs[s].col_idx[k] >= 0 && slabs[s].col_idx[k] < width);
+						blz_csr_free(&slabs[s]);
+					}
+				}
+	char path[1024];
+	snprintf(path, sizeof path, "%s/copy.mtx", scratch);
+	REQUIRE(blz_mm_save_coo(path, M) == BLZ_OK);
+	blz_coo L;
+	REQUIRE(blz_mm_load(path, prime, &L) == BLZ_OK);
+	REQUIRE(L.nnz == M->nnz && L.nrows == M->nrows && L.ncols == M->ncols);
+	for (int64_t k = 0; k < L.nnz; k++)
+		REQUIRE(L.i[k] == M->i[k] && L.j[k] == M->j[k] && L.x[k] == M->x[k] % prime);
+	blz_coo_free(&L);
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 3)
+		return 64;
+	const char *golden = argv[1], *scratch = argv[2];
+	char path[1024], kpath[1024];
+	const uint64_t primes[3] = { 65537, 1073741789, ((uint64_t)1 << 61) - 1 };
+	const char *names[4] = { "trefethen20", "quirks40x30", "wide120x260", "rand3000x2000" };
+	for (int m = 0; m < 4; m++)
+		for (int q = 0; q < 3; q++) {
+			blz_coo M;
+			snprintf(path, sizeof path, "%s/%s.mtx", golden, names[m]);
+			REQUIRE(blz_mm_load(path, primes[q], &M) == BLZ_OK);
+			matrix_round(&M, primes[q], scratch);
+			blz_coo_free(&M);
+		}
+	/* sizes that take the OpenMP paths (parser pieces, atomics CSR build, parallel writer) */
+	blz_coo S;
+	REQUIRE(blz_synth_coo(70000, 50000, 400000, 0x5A17, 0, primes[1], &S) == BLZ_OK);
+	matrix_round(&S, primes[1], scratch);
+	blz_coo P;
+	REQUIRE(blz_synth_coo(50000, 60000, 300000, 9, 1, primes[2], &P) == BLZ_OK);
+	matrix_round(&P, primes[2], scratch);
+	blz_coo_free(&P);
+	REQUIRE(blz_synth_coo(10, 3, 40, 1, 0, 7, &P) != BLZ_OK);		/* more entries per row than columns */
+
+	/* RNG, kernel writer, checker (zero block, wrong block, bad shapes), both word widths */
+	const int n = 4;
+	const int64_t rows = S.nrows;
+	uint64_t *v = malloc(sizeof *v * (size_t)(rows * n)), *pb = malloc(sizeof *pb * (size_t)(rows * n));
+	REQUIRE(v && pb);
+	REQUIRE(blz_rng_fill(v, rows * n, primes[1]) == BLZ_OK);
+	snprintf(path, sizeof path, "%s/copy.mtx", scratch);
+	REQUIRE(blz_mm_save_coo(path, &S) == BLZ_OK);
+	snprintf(kpath, sizeof kpath, "%s/k.mtx", scratch);
+	REQUIRE(blz_save_block(kpath, rows, n, v) == BLZ_OK);
+	int64_t bad_row = -1;
+	int bad_col = -1;
+	REQUIRE(blz_check_kernel(path, kpath, primes[1], 0, &bad_row, &bad_col) == 2 && bad_row >= 0);	/* random block: y != 0 */
+	REQUIRE(blz_check_kernel(path, kpath, primes[1], 1, &bad_row, &bad_col) < 0);			/* dimension mismatch */
+	REQUIRE(blz_check_kernel(path, kpath, 65537, 0, &bad_row, &bad_col) < 0);				/* entries >= prime */
+	memset(v, 0, sizeof *v * (size_t)(rows * n));
+	REQUIRE(blz_save_block(kpath, rows, n, v) == BLZ_OK);
+	REQUIRE(blz_check_kernel(path, kpath, primes[1], 0, &bad_row, &bad_col) == 1);			/* all zero */
+	REQUIRE(blz_check_kernel(path, path, primes[1], 0, &bad_row, &bad_col) < 0);			/* not an array file */
+	REQUIRE(blz_rng_fill(v, rows * n, primes[2]) == BLZ_OK);						/* words >= 2^32 */
+	REQUIRE(blz_save_block(kpath, rows, n, v) == BLZ_OK);
+	REQUIRE(blz_check_kernel(path, kpath, primes[2], 0, &bad_row, &bad_col) == 2);
+
+	/* checkpoints: binary round trip, mismatch, truncated file; the reference's text files */
+	REQUIRE(blz_rng_fill(pb, rows * n, primes[1]) == BLZ_OK);
+	REQUIRE(blz_rng_fill(v, rows * n, primes[1]) == BLZ_OK);
+	snprintf(kpath, sizeof kpath, "%s/ck.bin", scratch);
+	REQUIRE(blz_checkpoint_save(kpath, primes[1], n, 0, rows, 1234, v, pb) == BLZ_OK);
+	uint64_t *v2 = malloc(sizeof *v2 * (size_t)(rows * n)), *p2 = malloc(sizeof *p2 * (size_t)(rows * n));
+	int64_t its = 0;
+	REQUIRE(v2 && p2);
+	REQUIRE(blz_checkpoint_load(kpath, primes[1], n, 0, rows, &its, v2, p2) == BLZ_OK && its == 1234);
+	REQUIRE(!memcmp(v, v2, sizeof *v * (size_t)(rows * n)) && !memcmp(pb, p2, sizeof *pb * (size_t)(rows * n)));
+	REQUIRE(blz_checkpoint_load(kpath, primes[1], n + 1, 0, rows, &its, v2, p2) != BLZ_OK);
+	REQUIRE(blz_checkpoint_load(kpath, primes[1], n, 0, rows - 1, &its, v2, p2) != BLZ_OK);
+	FILE *f = fopen(kpath, "r+");
+	REQUIRE(f && ftruncate(fileno(f), 4096) == 0);
+	fclose(f);
+	REQUIRE(blz_checkpoint_load(kpath, primes[1], n, 0, rows, &its, v2, p2) != BLZ_OK);
+	const int64_t small_rows = 300, small_cols = 200;
+	REQUIRE(blz_checkpoint_save_ref_text(scratch, n, small_rows, small_cols, 17, 0.0, 1.0, v, pb, v, pb) == BLZ_OK);
+	REQUIRE(blz_checkpoint_load_ref_text(scratch, n, small_rows, small_cols, &its, v2, p2) == BLZ_OK && its == 17);
+	REQUIRE(!memcmp(v, v2, sizeof *v * (size_t)(small_rows * n)));
+	REQUIRE(blz_checkpoint_load_ref_text("/nonexistent-dir", n, small_rows, small_cols, &its, v2, p2) != BLZ_OK);
+
+	/* malformed matrix files */
+	static const char *bad_files[] = {
+		"", "%%MatrixMarket matrix coordinate integer general\n", "%%MatrixMarket matrix coordinate integer general\n3 3\n",
+		"%%MatrixMarket matrix coordinate integer general\n3 3 2\n1 1 1\n", "%%MatrixMarket matrix coordinate integer general\n3 3 1\n4 1 1\n",
+		"%%MatrixMarket matrix coordinate integer general\n-3 3 1\n1 1 1\n", "%%MatrixMarket matrix coordinate integer general\n3 3 1\n1 1 x\n",
+		"%%MatrixMarket matrix array real general\n3 3\n1\n", "garbage\n",
+	};
+	for (size_t k = 0; k < sizeof bad_files / sizeof *bad_files; k++) {
+		snprintf(path, sizeof path, "%s/bad.mtx", scratch);
+		f = fopen(path, "w");
+		REQUIRE(f);
+		fputs(bad_files[k], f);
+		fclose(f);
+		blz_coo B;
+		REQUIRE(blz_mm_load(path, 65537, &B) != BLZ_OK);
+		REQUIRE(blz_check_kernel(path, path, 65537, 0, &bad_row, &bad_col) < 0);
+	}
+	free(v);
+	free(pb);
+	free(v2);
+	free(p2);
+	blz_coo_free(&S);
+	puts("host half clean under ASan + UBSan");
+	return 0;
+}
