@@ -180,12 +180,12 @@ def main():
     if os.path.exists(tpath):
         for name, rec in json.load(open(tpath)).items():
             if name.startswith("k_spmv<") and "FETCH_SIZE_bytes_per_launch" in rec and "WRITE_SIZE_bytes_per_launch" in rec:
-                # gfx950 calibration (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies a 128-byte streaming request as
-                # 64 bytes, so the wide coalesced part of this kernel (col_idx, val, row_ptr) is counted at half and
-                # is added back; the 64-byte row gathers are counted at face value (FETCH_SIZE = nnz*64 B + stream/2
-                # to within 0.3 % on this kernel).
-                stream = ctx.matrix_stream_bytes(not right)      # as resident: row_ptr + packed (or plain) entries
-                traffic = rec["FETCH_SIZE_bytes_per_launch"] + stream / 2 + rec["WRITE_SIZE_bytes_per_launch"]
+                # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE = TCC_EA0_RDREQ x 64 B although every request
+                # is a 128-byte line fill, so it is doubled; WRITE_SIZE is exact.  The separate pass in
+                # profiles/r01_v6_gl7d19_pmc_l2_fabric.txt confirms it for this kernel: all of its 35.7 M L2->fabric
+                # read requests per launch are counted under TCC_EA0_RDREQ_128B -- a gathered 64-byte block row costs a
+                # whole 128-byte line.
+                traffic = 2 * rec["FETCH_SIZE_bytes_per_launch"] + rec["WRITE_SIZE_bytes_per_launch"]
                 traffic_src = os.path.relpath(tpath, ROOT)
 
     macs_per_step = 2 * M.nnz * n
@@ -220,11 +220,14 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
             "traffic_source": traffic_src,
+            # the same launch measured in bytes that actually cross the L2 <-> fabric boundary
+            "traffic_GBps": (traffic / (t_spmv_ms * 1e-3) / 1e9) if (traffic and t_spmv_ms) else None,
+            "traffic_frac_of_peak": (traffic / (t_spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and t_spmv_ms) else None,
             "alg_bytes_per_launch": alg_bytes,
             "ms_per_launch": t_spmv_ms,
-            # what this kernel is actually limited by: one fabric request per entry; the
-            # micro-benchmarked ceiling for random block-row gathers on MI355X is 54.7 G requests/s whatever the row
-            # size (profiles/r01_ubench_alu_and_gather.txt)
+            # what this kernel is actually limited by: one 128-byte line fill per entry; the
+            # micro-benchmarked ceiling for random block-row gathers on MI355X is 54.7 G rows/s whatever the row
+            # size up to 128 B (profiles/r01_ubench_alu_and_gather.txt) = 7.0 TB/s of line traffic
             "gathers_per_s": nnz1 / (t_spmv_ms * 1e-3) if t_spmv_ms else None,
             "gather_ceiling_per_s": 54.7e9,
         },
