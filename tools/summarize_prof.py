@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 csv output (kernel-trace stats + PMC passes) into a short per-kernel table.
 
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB-like units of 1024 bytes; on gfx950 FETCH_SIZE
-counts wide coalesced streaming reads at half their size (MI355X_MICROARCH.md, HBM section), so the raw value
-and the doubled value are both shown -- gathers of 32/64-byte rows are uncalibrated.
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB-like units of 1024 bytes; on gfx950 FETCH_SIZE is
+TCC_EA0_RDREQ x 64 B although the requests are 128-byte line fills (MI355X_MICROARCH.md, HBM section; confirmed for
+the gather kernels here by TCC_EA0_RDREQ_128B, profiles/r01_v6_gl7d19_pmc_l2_fabric.txt), so the raw value and the
+doubled value are both shown; the doubled one is the byte count.
 """
 import csv
 import glob
@@ -46,7 +47,7 @@ for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     print(f"== {ctr} per launch (rocprofv3 --pmc {ctr}); value x 1024 bytes ==")
     for k, (tot, cnt) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
         mean = tot / cnt
-        extra = f"  (x2 for wide streams: {mean*2*1024/1e6:10.1f} MB)" if ctr == "FETCH_SIZE" else ""
+        extra = f"  (x2 = bytes: {mean*2*1024/1e6:10.1f} MB)" if ctr == "FETCH_SIZE" else ""
         print(f"{k:70s} launches {cnt:6d}  mean {mean*1024/1e6:10.1f} MB{extra}")
         traffic[k][ctr + "_bytes_per_launch"] = mean * 1024
         traffic[k]["launches"] = cnt
