@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -407,9 +408,15 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 		if (c->ag_chunks > 0) {
 			K = c->ag_chunks;
 		} else {
+			/* Cutting a product into K pieces leaves 1/K of it exposed after the last all-gather but pays K
+			 * collective start-ups (and 6-30 % more product time): exposed time
+			 * T/K + K*t0 is smallest at K = sqrt(T/t0), with T = this rank's product at the measured
+			 * ~55 G gathers/s and t0 ~ 25 us per all-gather call.  Pieces stay above ~2 MB per slab. */
 			const int64_t rows = std::min(right ? M->ncols : M->nrows, right ? M->nrows : M->ncols) / nranks;
 			const int64_t slab_bytes = rows * c->cfg.n * c->cfg.word;
-			K = (int)std::max<int64_t>(1, std::min<int64_t>(4, slab_bytes / (2 << 20)));
+			const double t_prod_us = (double)M->nnz / nranks / 55e3, t0_us = 25.0;
+			const int64_t by_time = (int64_t)(std::sqrt(t_prod_us / t0_us) + 0.5);
+			K = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, by_time), slab_bytes / (2 << 20)));
 		}
 	}
 	c->bounds[0].assign((size_t)nranks + 1, 0);
