@@ -29,6 +29,15 @@ MODP_DEV u64 bperm64(u64 x, int src_lane_x4)
 	return ((u64)hi << 32) | lo;
 }
 
+/* residues of a 32-bit prime need one ds_bpermute, not two */
+template <bool NARROW>
+MODP_DEV u64 bperm_word(u64 x, int src_lane_x4)
+{
+	if (NARROW)
+		return (u64)(u32)__builtin_amdgcn_ds_bpermute(src_lane_x4, (int)(u32)x);
+	return bperm64(x, src_lane_x4);
+}
+
 MODP_DEV u64 shfl_xor64(u64 x, int mask)
 {
 	const u32 lo = (u32)__shfl_xor((int)(u32)x, mask, 64), hi = (u32)__shfl_xor((int)(u32)(x >> 32), mask, 64);
@@ -403,7 +412,7 @@ struct DotState {
 	{
 #pragma unroll
 		for (int q = 0; q < NT; q++) {
-			const u64 aq = q == 0 ? ai : bperm64(ai, (gbase + ((i + q) & (NT - 1))) * 4);
+			const u64 aq = q == 0 ? ai : bperm_word<std::is_same<A, AccS>::value>(ai, (gbase + ((i + q) & (NT - 1))) * 4);
 			acc_mac64(a1[q], vi, aq);
 			if (q < H)
 				acc_mac64(a2[q], ai, aq);
@@ -460,7 +469,7 @@ k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long ro
 	if (ctl->stop)
 		return;
 	/* the 8-register lazy accumulator while the register file allows (13 of them at NT = 8) */
-	using DotAcc = typename std::conditional<(NT <= 8 && sizeof(W) == 8), AccL, Acc>::type;
+	using DotAcc = typename std::conditional<sizeof(W) == 4, AccS, typename std::conditional<(NT <= 8), AccL, Acc>::type>::type;
 	using DS = DotState<DotAcc, MERS, NT>;
 	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
 	constexpr int GPB = BLOCK / NT;
@@ -500,7 +509,7 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 {
 	if (ctl->stop)
 		return;
-	using DS = DotState<Acc, MERS, NT>;
+	using DS = DotState<typename std::conditional<sizeof(W) == 4, AccS, Acc>::type, MERS, NT>;
 	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
 	__shared__ u32 spal_store[BLOCK];
 	const u32 *spal = pal ? spal_store : nullptr;
@@ -543,7 +552,7 @@ k_spmv_heavy(const int *__restrict__ ci, const u32 *__restrict__ va, const u32 *
 	if (ctl->stop)
 		return;
 	constexpr int NT = DOT ? G : 1;
-	using DS = DotState<Acc, MERS, NT>;
+	using DS = DotState<typename std::conditional<sizeof(W) == 4, AccS, Acc>::type, MERS, NT>;
 	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
 	__shared__ Acc slices[BLOCK / G][G];
 	__shared__ u32 spal_store[BLOCK];
@@ -588,7 +597,7 @@ k_spmv_heavy_combine(const HeavyRow *__restrict__ mrows, int nm, const u64 *__re
 	if (ctl->stop)
 		return;
 	constexpr int NT = DOT ? G : 1;
-	using DS = DotState<Acc, MERS, NT>;
+	using DS = DotState<typename std::conditional<sizeof(W) == 4, AccS, Acc>::type, MERS, NT>;
 	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
 	const int lane = threadIdx.x & (G - 1), gbase = (threadIdx.x & 63) - lane;
 	const int g0 = (blockIdx.x * BLOCK + threadIdx.x) / G, ng = gridDim.x * (BLOCK / G);
@@ -1220,12 +1229,13 @@ k_orthogonalize_fast(W *__restrict__ V, const W *__restrict__ AV, W *__restrict_
 		return;
 	constexpr int GPB = BLOCK / NT, NN = NT * NT;
 	const int t = threadIdx.x, lane = t & 63, j = t & (NT - 1), gbase = lane - j;
-	u64 cc[NT], vd[NT], ww[NT];
+	using CW = typename std::conditional<sizeof(W) == 4, u32, u64>::type;	/* coefficients are residues too */
+	CW cc[NT], vd[NT], ww[NT];
 #pragma unroll
 	for (int k = 0; k < NT; k++) {
-		ww[k] = small[2 * NN + k * NT + j];
-		cc[k] = small[4 * NN + k * NT + j];
-		vd[k] = small[5 * NN + k * NT + j];
+		ww[k] = (CW)small[2 * NN + k * NT + j];
+		cc[k] = (CW)small[4 * NN + k * NT + j];
+		vd[k] = (CW)small[5 * NN + k * NT + j];
 	}
 	const bool dj = small[3 * NN + j] != 0;
 	const long long g0 = (long long)blockIdx.x * GPB + t / NT, ng = (long long)gridDim.x * GPB;
@@ -1233,12 +1243,13 @@ k_orthogonalize_fast(W *__restrict__ V, const W *__restrict__ AV, W *__restrict_
 	for (long long r = g0; r < rows; r += ng) {
 		const size_t at = (size_t)r * NT + j;
 		const u64 vv = V[at], aa = AV[at], pp = P[at];
-		typename std::conditional<sizeof(W) == 8, AccL, Acc>::type av, ap;
+		typename std::conditional<sizeof(W) == 8, AccL, AccS>::type av, ap;
 		acc_set(av, dj ? aa : vv);
 		acc_set(ap, dj ? 0 : pp);
 #pragma unroll
 		for (int k = 0; k < NT; k++) {
-			const u64 vk = NT == 1 ? vv : bperm64(vv, src0 + 4 * k), pk = NT == 1 ? pp : bperm64(pp, src0 + 4 * k);
+			const u64 vk = NT == 1 ? vv : bperm_word<sizeof(W) == 4>(vv, src0 + 4 * k);
+			const u64 pk = NT == 1 ? pp : bperm_word<sizeof(W) == 4>(pp, src0 + 4 * k);
 			acc_mac64(av, vk, cc[k]);
 			acc_mac64(av, pk, vd[k]);
 			acc_mac64(ap, vk, ww[k]);

@@ -183,6 +183,34 @@ MODP_DEV u64 acc_reduce(const AccL &a, const ModP &m)
 	return reduce128<MERS>(hi, lo, m);
 }
 
+/*
+ * Accumulator for sums of products of 32-bit residues (p < 2^32, the reference's own domain): 96 bits, one
+ * v_mad_u64_u32 and one v_addc per MAC instead of the 128-bit sequence.  Same interface as Acc / AccL; the
+ * operands arrive as u64 and MUST be below 2^32.  Up to 2^32 products between reductions.
+ */
+struct AccS {
+	u64 lo;
+	u32 hi;
+};
+
+MODP_DEV void acc_zero(AccS &a) { a.lo = 0; a.hi = 0; }
+MODP_DEV void acc_set(AccS &a, u64 x) { a.lo = x; a.hi = 0; }
+
+MODP_DEV void acc_mac64(AccS &a, u64 x, u64 y)
+{
+	asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+	    "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+	    : "+v"(a.lo), "+v"(a.hi)
+	    : "v"((u32)x), "v"((u32)y)
+	    : "vcc");
+}
+
+template <int MERS>
+MODP_DEV u64 acc_reduce(const AccS &a, const ModP &m)
+{
+	return reduce128<MERS>((u64)a.hi, a.lo, m);
+}
+
 MODP_DEV u64 addmod(u64 x, u64 y, u64 p)
 {
 	const u64 s = x + y;		/* x, y < p < 2^62 */
