@@ -179,6 +179,7 @@ static void free_csr(DevCsr &A)
 	if (A.heavy) hipFree(A.heavy);
 	if (A.heavy_multi) hipFree(A.heavy_multi);
 	if (A.heavy_scratch) hipFree(A.heavy_scratch);
+	if (A.medium_rows) hipFree(A.medium_rows);
 	A = DevCsr{};
 }
 
@@ -238,7 +239,7 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	HIPCHK(hipEventCreate(&c->ev1));
 	HIPCHK(hipMalloc(&c->small, small_words(n) * sizeof(u64)));
 	HIPCHK(hipMemset(c->small, 0, small_words(n) * sizeof(u64)));
-	c->max_dot_blocks = c->cfg.num_cu * 8;
+	c->max_dot_blocks = c->cfg.num_cu * 16;	/* partial rows: streaming kernel + the outlier launches */
 	HIPCHK(hipMalloc(&c->partial, (size_t)c->max_dot_blocks * 2 * n * n * sizeof(u64)));
 	HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
@@ -337,11 +338,25 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
 	D.heavy_thr = spmv_heavy_threshold(c->cfg, H.rows, H.nnz);
 	std::vector<HeavySeg> heavy;
 	std::vector<HeavyRow> multi;
+	std::vector<int> medium;
+	int G = 1;
+	while (G < c->cfg.n)
+		G <<= 1;
+	/* up to 256 entries per lane group of the wavefront (64 batches of 4 gathers); with one group per wavefront
+	 * (n > 32) the tier is empty */
+	const u32 medium_max = G < 64 ? (u32)(64 / G) * 256u : 0u;
+	int64_t kept_rows = 0, kept_nnz = 0;
 	double sq = 0.0;
 	for (int64_t r = 0; r < H.rows; r++) {
 		const u32 k0 = H.row_ptr[r], len = H.row_ptr[r + 1] - k0;
 		if (len <= D.heavy_thr) {
 			sq += (double)len * (double)len;
+			kept_rows++;
+			kept_nnz += len;
+			continue;
+		}
+		if (len <= medium_max) {	/* one wavefront per row */
+			medium.push_back((int)r);
 			continue;
 		}
 		const u32 cnt = (len + HEAVY_SEG - 1) / HEAVY_SEG, per = (len + cnt - 1) / cnt;
@@ -350,23 +365,21 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
 		for (u32 q = 0; q < cnt; q++)
 			heavy.push_back(HeavySeg{(int)r, k0 + q * per, k0 + std::min(len, (q + 1) * per), cnt == 1});
 	}
-	{	/* spread of the rows the streaming kernel keeps */
-		int64_t lrows = H.rows, lnnz = H.nnz;
-		for (const HeavySeg &sg : heavy) {
-			lnnz -= sg.k1 - sg.k0;
-			if (sg.k0 == H.row_ptr[sg.row])
-				lrows--;
-		}
-		if (lrows > 0) {
-			const double mean = (double)lnnz / (double)lrows, var = sq / (double)lrows - mean * mean;
-			D.uneven = var > 0.25 * mean * mean;
-		}
+	if (kept_rows > 0) {	/* spread of the rows the streaming kernel keeps */
+		const double mean = (double)kept_nnz / (double)kept_rows, var = sq / (double)kept_rows - mean * mean;
+		D.uneven = var > 0.25 * mean * mean;
+		D.kept_mean = mean;
 	}
 	D.n_heavy = (int)heavy.size();
 	D.n_multi = (int)multi.size();
 	if (D.n_heavy) {
 		HIPCHK(hipMalloc(&D.heavy, heavy.size() * sizeof(HeavySeg)));
 		HIPCHK(hipMemcpy(D.heavy, heavy.data(), heavy.size() * sizeof(HeavySeg), hipMemcpyHostToDevice));
+	}
+	D.n_medium = (int)medium.size();
+	if (D.n_medium) {
+		HIPCHK(hipMalloc(&D.medium_rows, medium.size() * sizeof(int)));
+		HIPCHK(hipMemcpy(D.medium_rows, medium.data(), medium.size() * sizeof(int), hipMemcpyHostToDevice));
 	}
 	if (D.n_multi) {
 		HIPCHK(hipMalloc(&D.heavy_multi, multi.size() * sizeof(HeavyRow)));

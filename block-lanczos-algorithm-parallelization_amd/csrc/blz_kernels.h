@@ -28,6 +28,9 @@ struct DevCsr {
 	HeavyRow *heavy_multi = nullptr;	/* the rows among them that span several segments */
 	int n_multi = 0;
 	u64 *heavy_scratch = nullptr;	/* 128-bit partial sums: [segment][G lanes][lo, hi] */
+	int *medium_rows = nullptr;	/* rows above heavy_thr that one wavefront can take (k_spmv_wave) */
+	int n_medium = 0;
+	double kept_mean = -1.0;	/* mean length of the rows the streaming kernel keeps (< 0: nnz / rows) */
 	u32 heavy_thr = 0xFFFFFFFFu;
 	bool uneven = false;		/* row lengths vary a lot (std > mean/2): the SpMV wants more resident waves */
 };

@@ -151,7 +151,21 @@ k_spmv_heavy_combine(const HeavyRow *__restrict__ mrows, int nm, const u64 *__re
 		     const W *__restrict__ Vd, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
 		     const DevCtl *__restrict__ ctl);
 
-/* blocks of the two outlier launches: one per segment (bounded), and one per BLOCK/G split rows */
+template <typename W, int G, int MERS, bool DOT>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_wave(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
+	    const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
+	    const int *__restrict__ list, int nlist, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
+	    const DevCtl *__restrict__ ctl);
+
+/* blocks of the outlier launches: one wavefront per medium row (4 per block, bounded), one block per segment of a
+ * long row (bounded), and one lane group per split row */
+static inline long long medium_blocks(const KernelCfg &c, const DevCsr &A)
+{
+	const long long b = ((long long)A.n_medium + 3) / 4, cap = (long long)c.num_cu * 6;
+	return b < cap ? b : cap;
+}
+
 static inline long long heavy_blocks(const KernelCfg &c, const DevCsr &A, long long room)
 {
 	long long b = A.n_heavy < (long long)c.num_cu * 4 ? A.n_heavy : (long long)c.num_cu * 4;
@@ -168,12 +182,18 @@ template <typename W, int G, int MERS, bool DOT>
 static void launch_heavy(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum, u64 *partial,
 			 int slot0, long long hb, const DevCtl *ctl, hipStream_t s)
 {
-	hipLaunchKernelGGL((k_spmv_heavy<W, G, MERS, DOT>), dim3((unsigned)hb), dim3(BLOCK), 0, s, A.col_idx, A.val,
-			   A.palette, X, Y, Vd, A.heavy, A.n_heavy, A.heavy_scratch, c.n, accum, c.m, partial, slot0, ctl);
-	if (A.n_multi)
-		hipLaunchKernelGGL((k_spmv_heavy_combine<W, G, MERS, DOT>), dim3((unsigned)combine_blocks(A, G)), dim3(BLOCK),
+	if (hb)
+		hipLaunchKernelGGL((k_spmv_heavy<W, G, MERS, DOT>), dim3((unsigned)hb), dim3(BLOCK), 0, s, A.col_idx, A.val,
+				   A.palette, X, Y, Vd, A.heavy, A.n_heavy, A.heavy_scratch, c.n, accum, c.m, partial, slot0, ctl);
+	const long long cb = A.n_multi ? combine_blocks(A, G) : 0;
+	if (cb)
+		hipLaunchKernelGGL((k_spmv_heavy_combine<W, G, MERS, DOT>), dim3((unsigned)cb), dim3(BLOCK),
 				   0, s, A.heavy_multi, A.n_multi, A.heavy_scratch, Y, Vd, c.n, accum, c.m, partial,
 				   slot0 + (int)hb, ctl);
+	if (A.n_medium)
+		hipLaunchKernelGGL((k_spmv_wave<W, G, MERS, DOT>), dim3((unsigned)medium_blocks(c, A)), dim3(BLOCK), 0, s,
+				   A.row_ptr, A.col_idx, A.val, A.palette, X, Y, Vd, A.medium_rows, A.n_medium, c.n, accum, c.m,
+				   partial, slot0 + (int)(hb + cb), ctl);
 }
 
 template <typename W, int G, int MERS>
@@ -237,7 +257,9 @@ static int spmv_split_log2(const KernelCfg &c, int64_t rows, int64_t nnz)
 u32 spmv_heavy_threshold(const KernelCfg &c, int64_t rows, int64_t nnz)
 {
 	const double avg = rows ? (double)nnz / (double)rows : 0.0;
-	const u32 base = (u32)(4.0 * avg < 64.0 ? 64.0 : 4.0 * avg);
+	u32 base = (u32)(4.0 * avg < 64.0 ? 64.0 : 4.0 * avg);
+	if (const char *e = getenv("BLZ_HEAVY_THR"))	/* experiments only */
+		base = (u32)atoll(e);
 	return base << spmv_split_log2(c, rows, nnz);
 }
 
@@ -253,7 +275,7 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 	const long long groups_per_block = BLOCK / G;
 	/* measured on MI355X (tools/tune_spmv.py): rows of >= ~12 entries run best with 4 resident blocks per CU,
 	 * short rows want 8; few long rows are split over up to 64/G groups */
-	const double avg = (double)A.nnz / (double)A.rows;
+	const double avg = A.kept_mean >= 0.0 ? A.kept_mean : (double)A.nnz / (double)A.rows;	/* of the rows this launch takes */
 	const int split_log2 = spmv_split_log2(c, A.rows, A.nnz);
 	/* (128-byte block rows out of an HBM-sized X are the exception: they want the full 8, measured on the
 	 * config-5 shape) */
@@ -272,7 +294,7 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 		hipLaunchKernelGGL((k_spmv<W, GG, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr,  \
 				   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, accum,     \
 				   A.heavy_thr, c.m, ctl);                                                         \
-		if (A.n_heavy)                                                                                    \
+		if (A.n_heavy || A.n_medium)                                                                      \
 			launch_heavy<W, GG, MERS, false>(c, A, X, Y, (const W *)nullptr, accum, (u64 *)nullptr, 0,   \
 							 heavy_blocks(c, A, 1 << 30), ctl, s);                        \
 		break;
@@ -624,6 +646,55 @@ k_spmv_heavy_combine(const HeavyRow *__restrict__ mrows, int nm, const u64 *__re
 		ds.finish(red, partial, m, slot0 + (int)blockIdx.x);
 }
 
+/* Medium rows (longer than the outlier threshold, at most 256 entries per lane group of a wavefront): one wavefront
+ * per row -- its 64/G lane groups each sum a slice, the slices are added across lanes, group 0 finishes the row.  A
+ * workgroup per row (k_spmv_heavy) spends most of its time in barriers on rows of a few hundred entries. */
+template <typename W, int G, int MERS, bool DOT>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_wave(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
+	    const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
+	    const int *__restrict__ list, int nlist, int n, int accum, ModP m, u64 *__restrict__ partial, int slot0,
+	    const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int NT = DOT ? G : 1, GPW = 64 / G;
+	using DS = DotState<typename std::conditional<sizeof(W) == 4, AccS, Acc>::type, MERS, NT>;
+	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
+	__shared__ u32 spal_store[BLOCK];
+	const u32 *spal = pal ? spal_store : nullptr;
+	if (pal)
+		spal_store[threadIdx.x] = pal[threadIdx.x];
+	__syncthreads();
+	const int lane = threadIdx.x & (G - 1), wl = threadIdx.x & 63, grp = wl / G;
+	const int xl = lane < n ? lane : 0;
+	const int wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = (gridDim.x * BLOCK) >> 6;
+	DS ds;
+	if (DOT)
+		ds.init();
+	for (int h = wave; h < nlist; h += nwaves) {
+		const long long r = list[h];
+		const u32 k0 = rp[r], e0 = rp[r + 1];
+		const u32 per = (e0 - k0 + GPW - 1) / GPW, lo = k0 + (u32)grp * per;
+		Acc acc;
+		acc_zero(acc);
+		spmv_accumulate<W>(acc, lo < e0 ? lo : e0, (lo + per) < e0 ? (lo + per) : e0, ci, va, spal, X, n, xl);
+#pragma unroll
+		for (int off = G; off < 64; off <<= 1)
+			acc_add_acc(acc, shfl_xor64(acc.lo, off), shfl_xor64(acc.hi, off));
+		if (grp == 0 && lane < n) {
+			if (accum)
+				acc_add(acc, Y[(size_t)r * n + lane]);
+			const u64 y = acc_reduce<MERS>(acc, m);
+			Y[(size_t)r * n + lane] = (W)y;
+			if (DOT)
+				ds.row(Vd[(size_t)r * n + lane], y, lane, 0, m);
+		}
+	}
+	if (DOT)
+		ds.finish(red, partial, m, slot0 + (int)blockIdx.x);
+}
+
 template <typename W, int MERS>
 static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum,
 				    u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
@@ -633,16 +704,17 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 	/* the accumulators cost registers: 4 resident blocks per CU at n = 8, so size the grid for that */
 	const long long per_cu = c.n >= 8 ? 4 : 6;
 	/* partial rows: one per block of the streaming kernel, then one per block of the outlier-row launch */
-	const long long hb = heavy_blocks(c, A, max_blocks / 2), cb = A.n_multi ? combine_blocks(A, c.n) : 0;
-	const long long room = max_blocks - hb - cb;
+	const long long hb = heavy_blocks(c, A, max_blocks / 4), cb = A.n_multi ? combine_blocks(A, c.n) : 0;
+	const long long mb = A.n_medium ? medium_blocks(c, A) : 0;
+	const long long room = max_blocks - hb - cb - mb;
 	const long long cap = (long long)c.num_cu * per_cu < room ? (long long)c.num_cu * per_cu : room;
 	blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
-	*nblocks = (int)(blocks + hb + cb);
+	*nblocks = (int)(blocks + hb + cb + mb);
 #define SPMV_DOT(NN)                                                                                                \
 	case NN:                                                                                                    \
 		hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
 				   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, A.heavy_thr, c.m, partial, ctl); \
-		if (hb)                                                                                             \
+		if (hb || mb)                                                                                       \
 			launch_heavy<W, NN, MERS, true>(c, A, X, Y, Vd, accum, partial, (int)blocks, hb, ctl, s);      \
 		break;
 	switch (c.n) {
