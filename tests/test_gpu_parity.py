@@ -220,9 +220,11 @@ def outlier_matrix(p):
 @pytest.mark.parametrize("n,p", [(8, P61), (4, 2147483647), (16, 1073741789), (3, P61)])
 def test_outlier_rows_get_a_workgroup_each(n, p):
     """A few very dense rows and columns among short ones (the shape of real relation matrices): rows above
-    max(64, 4 x mean) entries are listed at upload, skipped by the streaming kernels and summed by k_spmv_heavy, one
-    workgroup per row -- including their share of the fused inner products (n = 8, 4, 16) and 100 ADJACENT rows of
-    600, which the renumbering keeps together.  Both orientations, through a whole solve."""
+    max(64, 4 x mean) entries are listed at upload and skipped by the streaming kernels; k_spmv_wave gives a wavefront
+    to the medium ones (here the 100 ADJACENT rows of 600, which the renumbering keeps together), k_spmv_heavy a
+    workgroup per 4096-entry segment to the long ones (3000 and 5000 entries: one and two segments, the latter
+    combined by k_spmv_heavy_combine) -- including their share of the fused inner products (n = 8, 4).  Both
+    orientations, through a whole solve."""
     M = outlier_matrix(p)
     for right in (False, True):
         want = orc.block_lanczos(as_orc(M), n, p, right=right, stop_after=3)
