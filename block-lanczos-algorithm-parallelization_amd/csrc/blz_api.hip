@@ -239,7 +239,9 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	HIPCHK(hipEventCreate(&c->ev1));
 	HIPCHK(hipMalloc(&c->small, small_words(n) * sizeof(u64)));
 	HIPCHK(hipMemset(c->small, 0, small_words(n) * sizeof(u64)));
-	c->max_dot_blocks = c->cfg.num_cu * 16;	/* partial rows: streaming kernel + the outlier launches */
+	/* partial rows of the inner products: the fused path (n <= 8) needs room for the streaming kernel plus the
+	 * outlier launches; the stand-alone kernel keeps the grid it was tuned with */
+	c->max_dot_blocks = c->cfg.num_cu * (n <= 8 ? 16 : 8);
 	HIPCHK(hipMalloc(&c->partial, (size_t)c->max_dot_blocks * 2 * n * n * sizeof(u64)));
 	HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
@@ -831,7 +833,7 @@ static int enqueue_dot(blz_ctx *c)
 	{
 	Span sp(c, PK_DOT);
 	HIPCHK(launch_block_dot(c->cfg, slab_ptr(c, BLZ_V), slab_ptr(c, BLZ_AV), c->count[0], c->partial,
-				c->max_dot_blocks, &nb, c->ctl, c->stream));
+				std::min(c->max_dot_blocks, c->cfg.num_cu * 8), &nb, c->ctl, c->stream));
 	HIPCHK(launch_dot_finalize(c->cfg, c->partial, nb, c->small, c->ctl, c->stream));
 	}
 	return allreduce_dots(c);
