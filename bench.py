@@ -100,6 +100,8 @@ def main():
         dist.init_process_group(backend="gloo", init_method="env://")
     if blz.device_count() < 1:
         sys.exit("bench.py: no GPU visible -- libblz_hip has no CPU path")
+    # one GPU per rank; if the launcher narrowed the visibility to one device per process, that device is number 0
+    local_rank %= blz.device_count()
     torch.cuda.set_device(local_rank)
 
     w = WORKLOADS[args.workload]
