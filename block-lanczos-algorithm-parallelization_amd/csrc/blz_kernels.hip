@@ -277,14 +277,15 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 	 * short rows want 8; few long rows are split over up to 64/G groups */
 	const double avg = A.kept_mean >= 0.0 ? A.kept_mean : (double)A.nnz / (double)A.rows;	/* of the rows this launch takes */
 	const int split_log2 = spmv_split_log2(c, A.rows, A.nnz);
-	/* (128-byte block rows out of an HBM-sized X are the exception: they want the full 8, measured on the
-	 * config-5 shape) */
-	const bool wide_rows_from_hbm = (size_t)G * sizeof(W) >= 128 && (double)A.cols * c.n * sizeof(W) > 256e6;
+	/* (widths of 16 and more are the exception: a wavefront then holds 4 lane groups or fewer, i.e. at most 16 line
+	 * fills in flight with the 4-deep batch, and 16 waves per CU cannot cover the fabric latency: 8 blocks per CU,
+	 * measured 1052 -> 724 us at n = 16 on the GL7d19 shape and the same on the config-5 shape) */
+	const bool few_groups_per_wave = G >= 16;
 	/* (and so are uneven row lengths: lane groups that have finished their row wait for the longest one of their
 	 * wavefront and issue nothing meanwhile, so more resident wavefronts are needed to keep the fabric busy --
 	 * tools/exp_skew.py, 4 -> 6 blocks per CU: -9 % on lognormal lengths) */
 	int per_cu = c.spmv_blocks_per_cu > 0 ? c.spmv_blocks_per_cu
-					      : ((avg / (1 << split_log2) >= 12.0 && !wide_rows_from_hbm) ? (A.uneven ? 6 : 4) : 8);
+					      : ((avg / (1 << split_log2) >= 12.0 && !few_groups_per_wave) ? (A.uneven ? 6 : 4) : 8);
 	long long blocks = ((A.rows << split_log2) + groups_per_block - 1) / groups_per_block;
 	const long long cap = (long long)c.num_cu * per_cu;
 	if (blocks > cap)
