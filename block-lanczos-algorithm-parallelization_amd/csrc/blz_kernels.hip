@@ -38,6 +38,36 @@ MODP_DEV u64 bperm_word(u64 x, int src_lane_x4)
 	return bperm64(x, src_lane_x4);
 }
 
+/* Broadcast of lane K of every lane group to the whole group as VALU moves (DPP row_newbcast, one 16-lane row =
+ * one group at NT = 16; two half-row moves at NT = 8) -- no LDS crossbar traffic, no lgkmcnt wait. */
+template <int K, int NT>
+MODP_DEV u32 group_bcast32(u32 x)
+{
+	static_assert(NT == 16 || NT == 8, "row_newbcast covers groups of 8 or 16 lanes");
+	if (NT == 16)
+		return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + K, 0xF, 0xF, false);
+	const int lo = __builtin_amdgcn_update_dpp(0, (int)x, 0x150 + (K & 7), 0xF, 0x3, false);
+	return (u32)__builtin_amdgcn_update_dpp(lo, (int)x, 0x150 + 8 + (K & 7), 0xF, 0xC, false);
+}
+
+template <int K, int NT, bool NARROW>
+MODP_DEV u64 group_bcast(u64 x)
+{
+	const u32 lo = group_bcast32<K, NT>((u32)x);
+	if (NARROW)
+		return lo;
+	return ((u64)group_bcast32<K, NT>((u32)(x >> 32)) << 32) | lo;
+}
+
+template <int K, int N, class F>
+MODP_DEV void static_for(F &&f)
+{
+	if constexpr (K < N) {
+		f(std::integral_constant<int, K>{});
+		static_for<K + 1, N>(f);
+	}
+}
+
 MODP_DEV u64 shfl_xor64(u64 x, int mask)
 {
 	const u32 lo = (u32)__shfl_xor((int)(u32)x, mask, 64), hi = (u32)__shfl_xor((int)(u32)(x >> 32), mask, 64);
@@ -1319,13 +1349,23 @@ k_orthogonalize_fast(W *__restrict__ V, const W *__restrict__ AV, W *__restrict_
 		typename std::conditional<sizeof(W) == 8, AccL, AccS>::type av, ap;
 		acc_set(av, dj ? aa : vv);
 		acc_set(ap, dj ? 0 : pp);
+		if constexpr (NT == 16) {	/* one DPP row = one group; at NT = 8 the two half-row moves cost more than they save */
+			static_for<0, NT>([&](auto kc) {
+				constexpr int k = decltype(kc)::value;
+				const u64 vk = group_bcast<k, NT, sizeof(W) == 4>(vv), pk = group_bcast<k, NT, sizeof(W) == 4>(pp);
+				acc_mac64(av, vk, cc[k]);
+				acc_mac64(av, pk, vd[k]);
+				acc_mac64(ap, vk, ww[k]);
+			});
+		} else {
 #pragma unroll
-		for (int k = 0; k < NT; k++) {
-			const u64 vk = NT == 1 ? vv : bperm_word<sizeof(W) == 4>(vv, src0 + 4 * k);
-			const u64 pk = NT == 1 ? pp : bperm_word<sizeof(W) == 4>(pp, src0 + 4 * k);
-			acc_mac64(av, vk, cc[k]);
-			acc_mac64(av, pk, vd[k]);
-			acc_mac64(ap, vk, ww[k]);
+			for (int k = 0; k < NT; k++) {
+				const u64 vk = NT == 1 ? vv : bperm_word<sizeof(W) == 4>(vv, src0 + 4 * k);
+				const u64 pk = NT == 1 ? pp : bperm_word<sizeof(W) == 4>(pp, src0 + 4 * k);
+				acc_mac64(av, vk, cc[k]);
+				acc_mac64(av, pk, vd[k]);
+				acc_mac64(ap, vk, ww[k]);
+			}
 		}
 		V[at] = (W)acc_reduce<MERS>(av, m);
 		P[at] = (W)acc_reduce<MERS>(ap, m);
