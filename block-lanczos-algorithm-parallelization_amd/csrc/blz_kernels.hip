@@ -59,6 +59,18 @@ MODP_DEV u64 group_bcast(u64 x)
 	return ((u64)group_bcast32<K, NT>((u32)(x >> 32)) << 32) | lo;
 }
 
+/* lane i of every 16-lane row receives the word of lane (i + Q) mod 16: DPP row_ror by 16 - Q, one VALU move per
+ * 32 bits */
+template <int Q, bool NARROW>
+MODP_DEV u64 row16_rotl(u64 x)
+{
+	static_assert(Q >= 1 && Q <= 15, "rotation inside a row of 16");
+	const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)x, 0x120 + (16 - Q), 0xF, 0xF, false);
+	if (NARROW)
+		return lo;
+	return ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(x >> 32), 0x120 + (16 - Q), 0xF, 0xF, false) << 32) | lo;
+}
+
 template <int K, int N, class F>
 MODP_DEV void static_for(F &&f)
 {
@@ -463,12 +475,26 @@ struct DotState {
 	/* one block row: vi = v[r,i], ai = Av[r,i]; gbase = first lane of the group within the wavefront */
 	__device__ __forceinline__ void row(u64 vi, u64 ai, int i, int gbase, const ModP &m)
 	{
+		if constexpr (NT == 16 && std::is_same<A, AccS>::value) {
+			/* a group is one DPP row: rotate with VALU moves, not through the LDS crossbar (32-bit words: -10 %; at
+			 * 64 bits the kernel is VALU-bound and the extra moves cost 3 %) */
+			acc_mac64(a1[0], vi, ai);
+			acc_mac64(a2[0], ai, ai);
+			static_for<1, NT>([&](auto qc) {
+				constexpr int q = decltype(qc)::value;
+				const u64 aq = row16_rotl<q, std::is_same<A, AccS>::value>(ai);
+				acc_mac64(a1[q], vi, aq);
+				if constexpr (q < H)
+					acc_mac64(a2[q], ai, aq);
+			});
+		} else {
 #pragma unroll
-		for (int q = 0; q < NT; q++) {
-			const u64 aq = q == 0 ? ai : bperm_word<std::is_same<A, AccS>::value>(ai, (gbase + ((i + q) & (NT - 1))) * 4);
-			acc_mac64(a1[q], vi, aq);
-			if (q < H)
-				acc_mac64(a2[q], ai, aq);
+			for (int q = 0; q < NT; q++) {
+				const u64 aq = q == 0 ? ai : bperm_word<std::is_same<A, AccS>::value>(ai, (gbase + ((i + q) & (NT - 1))) * 4);
+				acc_mac64(a1[q], vi, aq);
+				if (q < H)
+					acc_mac64(a2[q], ai, aq);
+			}
 		}
 		if (++cnt == m.chunk) {
 			cnt = 0;
