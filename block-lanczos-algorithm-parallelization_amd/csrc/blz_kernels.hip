@@ -806,7 +806,7 @@ static hipError_t dot_dispatch(const KernelCfg &c, const W *V, const W *AV, int6
 			       int *nblocks, const DevCtl *ctl, hipStream_t s)
 {
 	const int n = c.n, pairs = n * n;
-	if (n == 1 || n == 2 || n == 4 || n == 8 || n == 16) {
+	if (n == 1 || n == 2 || n == 4 || n == 8 || n == 16 || n == 32) {
 		const long long gpb = BLOCK / n;
 		long long blocks = (rows + gpb * 8 - 1) / (gpb * 8);	/* >= 8 rows per group */
 		blocks = blocks < 1 ? 1 : (blocks > max_blocks ? max_blocks : blocks);
@@ -822,6 +822,7 @@ static hipError_t dot_dispatch(const KernelCfg &c, const W *V, const W *AV, int6
 			DOT_FAST(4)
 			DOT_FAST(8)
 			DOT_FAST(16)
+			DOT_FAST(32)
 		}
 #undef DOT_FAST
 		return hipGetLastError();

@@ -137,6 +137,19 @@ def test_every_block_width(n):
     assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
 
 
+@pytest.mark.parametrize("p", [P61, (1 << 62) - 57, 2147483647, 1073741789])
+@pytest.mark.parametrize("n", [16, 32])
+def test_wide_blocks_with_every_kind_of_word(n, p):
+    """n = 16 and 32 take their own register-resident inner-product kernels (49 accumulators per lane at n = 32) and,
+    at n = 16, DPP broadcasts in the update: every reducer (Mersenne 61 / 31, Barrett at 64 and 32 bits) on a matrix
+    large enough for several workgroups."""
+    M, Mo = load_both("rand3000x2000", p)
+    want = orc.block_lanczos(Mo, n, p, stop_after=5)
+    got = blz.solve(M, p, n, stop_after=5, batch=5)
+    assert got["iterations"] == 5
+    assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
+
+
 def test_n_out_of_range_and_bad_prime_are_errors():
     for (p, n) in ((65537, 0), (65537, 65), (1, 4), (0, 4), (1 << 62, 4)):
         with pytest.raises(blz.BlzError) as e:
