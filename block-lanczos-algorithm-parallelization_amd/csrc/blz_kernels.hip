@@ -1399,6 +1399,61 @@ k_orthogonalize_fast(W *__restrict__ V, const W *__restrict__ AV, W *__restrict_
 	}
 }
 
+/*
+ * n = 32: one wavefront per block row, lane = (h, j): output column j, and the half h of the sum over k (k in
+ * [16h, 16h + 16)), so that a lane keeps 3 * 16 coefficient words like the n = 16 kernel instead of 3 * 32.  Each
+ * 16-lane DPP row loads the 16 words v[r, 16h ..], p[r, 16h ..] it has to broadcast (row_newbcast); the two halves
+ * are reduced separately and added mod p across lane L and L ^ 32.
+ */
+template <typename W, int MERS>
+__global__ void __launch_bounds__(BLOCK)
+k_orthogonalize_32(W *__restrict__ V, const W *__restrict__ AV, W *__restrict__ P, long long rows, ModP m,
+		   const u64 *__restrict__ small, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int NT = 32, NN = NT * NT, HK = 16;
+	constexpr bool NARROW = sizeof(W) == 4;
+	const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, k0 = HK * h;
+	using CW = typename std::conditional<NARROW, u32, u64>::type;
+	CW cc[HK], vd[HK], ww[HK];
+#pragma unroll
+	for (int kk = 0; kk < HK; kk++) {
+		ww[kk] = (CW)small[2 * NN + (k0 + kk) * NT + j];
+		cc[kk] = (CW)small[4 * NN + (k0 + kk) * NT + j];
+		vd[kk] = (CW)small[5 * NN + (k0 + kk) * NT + j];
+	}
+	const bool dj = small[3 * NN + j] != 0;
+	const long long w0 = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 6, nw = ((long long)gridDim.x * BLOCK) >> 6;
+	for (long long r = w0; r < rows; r += nw) {
+		const size_t row = (size_t)r * NT;
+		const u64 bv = V[row + k0 + (lane & 15)], bp = P[row + k0 + (lane & 15)];	/* to broadcast */
+		u64 vj = 0, aj = 0, pj = 0;							/* own column: half 0 adds it */
+		if (h == 0) {
+			vj = V[row + j];
+			aj = AV[row + j];
+			pj = P[row + j];
+		}
+		typename std::conditional<NARROW, AccS, AccL>::type av, ap;
+		acc_set(av, h ? 0 : (dj ? aj : vj));
+		acc_set(ap, (h || dj) ? 0 : pj);
+		static_for<0, HK>([&](auto kc) {
+			constexpr int kk = decltype(kc)::value;
+			const u64 vk = group_bcast<kk, 16, NARROW>(bv), pk = group_bcast<kk, 16, NARROW>(bp);
+			acc_mac64(av, vk, cc[kk]);
+			acc_mac64(av, pk, vd[kk]);
+			acc_mac64(ap, vk, ww[kk]);
+		});
+		u64 rv = acc_reduce<MERS>(av, m), rp = acc_reduce<MERS>(ap, m);
+		rv = addmod(rv, shfl_xor64(rv, 32), m.p);
+		rp = addmod(rp, shfl_xor64(rp, 32), m.p);
+		if (h == 0) {
+			V[row + j] = (W)rv;
+			P[row + j] = (W)rp;
+		}
+	}
+}
+
 template <typename W, int MERS>
 static hipError_t ortho_dispatch(const KernelCfg &c, W *V, const W *AV, W *P, int64_t rows, const u64 *small,
 				 const DevCtl *ctl, hipStream_t s)
@@ -1407,6 +1462,15 @@ static hipError_t ortho_dispatch(const KernelCfg &c, W *V, const W *AV, W *P, in
 		return hipSuccess;
 	const int n = c.n;
 	const long long cap = (long long)c.num_cu * 8;
+	if (n == 32 && c.m.chunk >= 32u) {	/* 2 * 16 products per half-sum */
+		long long blocks = (rows + 3) / 4;
+		const long long fit = (long long)c.num_cu * (sizeof(W) == 4 ? 6 : 3);	/* what the registers let be resident */
+		if (blocks > fit)
+			blocks = fit;
+		hipLaunchKernelGGL((k_orthogonalize_32<W, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, P,
+				   (long long)rows, c.m, small, ctl);
+		return hipGetLastError();
+	}
 	if ((n == 1 || n == 2 || n == 4 || n == 8 || n == 16) && c.m.chunk >= 2u * (unsigned)n) {
 		const long long gpb = BLOCK / n;
 		long long blocks = (rows + gpb - 1) / gpb;
