@@ -9,6 +9,7 @@
  */
 #include "blz_kernels.h"
 
+#include <algorithm>
 #include <type_traits>
 
 #define BLOCK 256
@@ -573,6 +574,65 @@ k_block_dot_fast(const W *__restrict__ V, const W *__restrict__ AV, long long ro
 }
 
 /*
+ * n = 64: a block row is one wavefront wide, lane i holds v[r,i] and Av[r,i].  The 64 + 33 rotations do not fit the
+ * register file at once, so the rows are walked four times, 16 rotations (and, below 33, 16 symmetric-product terms)
+ * per pass; V and AV come out of L2 / the Infinity Cache on the later passes.  Every wavefront writes its own partial
+ * row, so there is no cross-wave reduction and no LDS.
+ */
+template <typename W, int MERS>
+__global__ void __launch_bounds__(BLOCK)
+k_block_dot_64(const W *__restrict__ V, const W *__restrict__ AV, long long rows, ModP m, u64 *__restrict__ partial,
+	       const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int NT = 64, QN = 16, H = NT / 2 + 1;
+	constexpr bool NARROW = sizeof(W) == 4;
+	using A = typename std::conditional<NARROW, AccS, Acc>::type;
+	const int i = threadIdx.x & 63;
+	const long long w0 = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 6, nw = ((long long)gridDim.x * BLOCK) >> 6;
+	u64 *out = partial + (size_t)w0 * 2 * NT * NT;
+	for (int qlo = 0; qlo < NT; qlo += QN) {
+		A a1[QN], a2[QN];
+#pragma unroll
+		for (int q = 0; q < QN; q++) {
+			acc_zero(a1[q]);
+			acc_zero(a2[q]);
+		}
+		u32 cnt = 0;
+		for (long long r = w0; r < rows; r += nw) {
+			const u64 vi = V[(size_t)r * NT + i], ai = AV[(size_t)r * NT + i];
+#pragma unroll
+			for (int q = 0; q < QN; q++) {
+				const int src = ((i + qlo + q) & (NT - 1)) * 4;
+				const u64 aq = bperm_word<NARROW>(ai, src);
+				acc_mac64(a1[q], vi, aq);
+				if (qlo + q < H)		/* uniform: whole passes or the single term q = 32 */
+					acc_mac64(a2[q], ai, aq);
+			}
+			if (++cnt == m.chunk) {
+				cnt = 0;
+#pragma unroll
+				for (int q = 0; q < QN; q++) {
+					acc_set(a1[q], acc_reduce<MERS>(a1[q], m));
+					acc_set(a2[q], acc_reduce<MERS>(a2[q], m));
+				}
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < QN; q++) {
+			const int jj = (i + qlo + q) & (NT - 1);
+			out[i * NT + jj] = acc_reduce<MERS>(a1[q], m);
+			if (qlo + q < H) {
+				const u64 x = acc_reduce<MERS>(a2[q], m);
+				out[NT * NT + i * NT + jj] = x;
+				out[NT * NT + jj * NT + i] = x;
+			}
+		}
+	}
+}
+
+/*
  * Second SpMV of an iteration (Av = M tmp, sequential/lanczos_modp.c:636) with block_dot_products (:640) as its
  * epilogue: the lane that has just produced Av[r,i] loads v[r,i] and feeds both products.  The SpMV is bound by
  * the gather request rate and leaves the VALU idle ~90 % of the time, so the n x n work is free here and the
@@ -806,6 +866,15 @@ static hipError_t dot_dispatch(const KernelCfg &c, const W *V, const W *AV, int6
 			       int *nblocks, const DevCtl *ctl, hipStream_t s)
 {
 	const int n = c.n, pairs = n * n;
+	if (n == 64) {	/* one partial row per WAVEFRONT: at most max_blocks of them */
+		long long blocks = (rows + 4 * 16 - 1) / (4 * 16);	/* >= 16 rows per wavefront */
+		const long long cap = std::min<long long>(max_blocks / 4, (long long)c.num_cu * 2);
+		blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+		*nblocks = (int)blocks * 4;
+		hipLaunchKernelGGL((k_block_dot_64<W, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, (long long)rows,
+				   c.m, partial, ctl);
+		return hipGetLastError();
+	}
 	if (n == 1 || n == 2 || n == 4 || n == 8 || n == 16 || n == 32) {
 		const long long gpb = BLOCK / n;
 		long long blocks = (rows + gpb * 8 - 1) / (gpb * 8);	/* >= 8 rows per group */
@@ -1454,6 +1523,67 @@ k_orthogonalize_32(W *__restrict__ V, const W *__restrict__ AV, W *__restrict__ 
 	}
 }
 
+/*
+ * n = 64: one workgroup per block row; wavefront q takes the quarter k in [16q, 16q + 16) of the sum for all 64 output
+ * columns (3 * 16 coefficient words per lane, operands by row_newbcast as at n = 32), the four partial residues are
+ * added through LDS and wavefront 0 stores the row.
+ */
+template <typename W, int MERS>
+__global__ void __launch_bounds__(BLOCK)
+k_orthogonalize_64(W *__restrict__ V, const W *__restrict__ AV, W *__restrict__ P, long long rows, ModP m,
+		   const u64 *__restrict__ small, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int NT = 64, NN = NT * NT, HK = 16;
+	constexpr bool NARROW = sizeof(W) == 4;
+	__shared__ u64 red[2][2][4][NT];
+	const int j = threadIdx.x & 63, q4 = threadIdx.x >> 6, k0 = HK * q4;
+	using CW = typename std::conditional<NARROW, u32, u64>::type;
+	CW cc[HK], vd[HK], ww[HK];
+#pragma unroll
+	for (int kk = 0; kk < HK; kk++) {
+		ww[kk] = (CW)small[2 * NN + (k0 + kk) * NT + j];
+		cc[kk] = (CW)small[4 * NN + (k0 + kk) * NT + j];
+		vd[kk] = (CW)small[5 * NN + (k0 + kk) * NT + j];
+	}
+	const bool dj = small[3 * NN + j] != 0;
+	int par = 0;
+	for (long long r = blockIdx.x; r < rows; r += gridDim.x, par ^= 1) {
+		const size_t row = (size_t)r * NT;
+		const u64 bv = V[row + k0 + (j & 15)], bp = P[row + k0 + (j & 15)];
+		u64 vj = 0, aj = 0, pj = 0;
+		if (q4 == 0) {
+			vj = V[row + j];
+			aj = AV[row + j];
+			pj = P[row + j];
+		}
+		typename std::conditional<NARROW, AccS, AccL>::type av, ap;
+		acc_set(av, q4 ? 0 : (dj ? aj : vj));
+		acc_set(ap, (q4 || dj) ? 0 : pj);
+		static_for<0, HK>([&](auto kc) {
+			constexpr int kk = decltype(kc)::value;
+			const u64 vk = group_bcast<kk, 16, NARROW>(bv), pk = group_bcast<kk, 16, NARROW>(bp);
+			acc_mac64(av, vk, cc[kk]);
+			acc_mac64(av, pk, vd[kk]);
+			acc_mac64(ap, vk, ww[kk]);
+		});
+		red[par][0][q4][j] = acc_reduce<MERS>(av, m);
+		red[par][1][q4][j] = acc_reduce<MERS>(ap, m);
+		__syncthreads();	/* also: every wavefront has read row r before wavefront 0 overwrites it */
+		if (q4 == 0) {
+			u64 rv = red[par][0][0][j], rp = red[par][1][0][j];
+#pragma unroll
+			for (int w = 1; w < 4; w++) {
+				rv = addmod(rv, red[par][0][w][j], m.p);
+				rp = addmod(rp, red[par][1][w][j], m.p);
+			}
+			V[row + j] = (W)rv;
+			P[row + j] = (W)rp;
+		}
+	}
+}
+
 template <typename W, int MERS>
 static hipError_t ortho_dispatch(const KernelCfg &c, W *V, const W *AV, W *P, int64_t rows, const u64 *small,
 				 const DevCtl *ctl, hipStream_t s)
@@ -1462,6 +1592,15 @@ static hipError_t ortho_dispatch(const KernelCfg &c, W *V, const W *AV, W *P, in
 		return hipSuccess;
 	const int n = c.n;
 	const long long cap = (long long)c.num_cu * 8;
+	if (n == 64 && c.m.chunk >= 32u) {
+		long long blocks = rows;
+		const long long fit = (long long)c.num_cu * (sizeof(W) == 4 ? 6 : 3);
+		if (blocks > fit)
+			blocks = fit;
+		hipLaunchKernelGGL((k_orthogonalize_64<W, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, P,
+				   (long long)rows, c.m, small, ctl);
+		return hipGetLastError();
+	}
 	if (n == 32 && c.m.chunk >= 32u) {	/* 2 * 16 products per half-sum */
 		long long blocks = (rows + 3) / 4;
 		const long long fit = (long long)c.num_cu * (sizeof(W) == 4 ? 6 : 3);	/* what the registers let be resident */

@@ -138,11 +138,11 @@ def test_every_block_width(n):
 
 
 @pytest.mark.parametrize("p", [P61, (1 << 62) - 57, 2147483647, 1073741789])
-@pytest.mark.parametrize("n", [16, 32])
+@pytest.mark.parametrize("n", [16, 32, 64])
 def test_wide_blocks_with_every_kind_of_word(n, p):
-    """n = 16 and 32 take their own register-resident inner-product kernels (49 accumulators per lane at n = 32) and,
-    at n = 16, DPP broadcasts in the update: every reducer (Mersenne 61 / 31, Barrett at 64 and 32 bits) on a matrix
-    large enough for several workgroups."""
+    """n = 16, 32 and 64 take their own inner-product and update kernels (49 accumulators per lane at n = 32, four
+    passes of 16 rotations at n = 64; DPP broadcasts, half- and quarter-sums joined across lanes or through LDS):
+    every reducer (Mersenne 61 / 31, Barrett at 64 and 32 bits) on a matrix large enough for several workgroups."""
     M, Mo = load_both("rand3000x2000", p)
     want = orc.block_lanczos(Mo, n, p, stop_after=5)
     got = blz.solve(M, p, n, stop_after=5, batch=5)
