@@ -998,13 +998,20 @@ __device__ static u64 dev_invmod(u64 a, u64 p)
 template <int MERS>
 __device__ static int ff_sweep(u64 *A, u64 *Wm, u64 *S, int n, int G, const ModP &m, u64 *mask)
 {
-	const int lane = threadIdx.x, li = lane / G, k = lane % G, RP = 64 / G;
+	/* T = blockDim.x threads (a multiple of 64, at least G*... one wavefront for small n): thread = (row of the pass,
+	 * column); the pivot search is a ballot in wavefront 0 (n <= 64 rows), published through LDS */
+	const int lane = threadIdx.x, li = lane / G, k = lane % G, RP = (int)blockDim.x / G;
+	__shared__ unsigned long long cand_sh;
 	int found = 0;
 	u64 bits = 0;
 	for (int j = 0; j < n; j++) {
 		__syncthreads();
 		const u64 probe = (lane < n && lane >= j) ? A[lane * n + j] : 0;
-		const unsigned long long cand = __ballot(probe != 0);
+		const unsigned long long mine = __ballot(probe != 0);
+		if (lane == 0)
+			cand_sh = mine;
+		__syncthreads();
+		const unsigned long long cand = cand_sh;
 		if (cand == 0)
 			continue;
 		const int piv = __ffsll(cand) - 1;
@@ -1074,7 +1081,7 @@ __device__ static int ff_sweep(u64 *A, u64 *Wm, u64 *S, int n, int G, const ModP
  * small = [vtAv | vtAAv | winv | d | c | vtAvd].  One wavefront.
  */
 template <int MERS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(1024)
 k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, ModP m, int in_loop)
 {
 	/* in_loop = 0: stand-alone call (blz_semi_inverse): neither obeys nor sets the sticky stop flag */
@@ -1083,20 +1090,21 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	const int nn = n * n;
 	u64 *A = (u64 *)smem_raw, *Wm = A + nn, *S = Wm + nn, *Pre = S + n;
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x, T = (int)blockDim.x;
 	u64 *vtAv = small, *vtAAv = small + nn, *winv = small + 2 * nn, *dvec = small + 3 * nn;
 	u64 *cmat = small + 4 * nn, *vtAvd = small + 5 * nn;
 
 	/* inputs may be sums of per-rank residues: bring them back into [0,p) */
-	for (int e = lane; e < nn; e += 64) {
+	for (int e = lane; e < nn; e += T) {
 		const u64 x = reduce128<MERS>(0, vtAv[e], m), y = reduce128<MERS>(0, vtAAv[e], m);
 		vtAv[e] = x;
 		vtAAv[e] = y;
 		A[e] = x;
 	}
 	u64 sel = 0, dbits = 0;
+	__syncthreads();
 	ff_sweep<MERS>(A, nullptr, nullptr, n, G, m, &sel);		/* phase 1, :349-382: which columns */
-	for (int e = lane; e < nn; e += 64) {				/* :384-388 */
+	for (int e = lane; e < nn; e += T) {				/* :384-388 */
 		const int i = e / n, j = e % n;
 		const bool both = ((sel >> i) & 1) && ((sel >> j) & 1);
 		A[e] = both ? vtAv[e] : 0;
@@ -1104,6 +1112,7 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, 
 	}
 	if (lane < n)
 		S[lane] = 1;
+	__syncthreads();
 	const int npiv = ff_sweep<MERS>(A, Wm, S, n, G, m, &dbits);	/* phase 2, :389-436 */
 	/* 1/s_i for all rows from one inversion: Pre[i] = s_0..s_i, then walk back */
 	if (lane == 0) {
@@ -1120,7 +1129,7 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, 
 		}
 	}
 	__syncthreads();
-	for (int e = lane; e < nn; e += 64) {
+	for (int e = lane; e < nn; e += T) {
 		const u64 w = mulmod<MERS>(Wm[e], S[e / n], m);
 		Wm[e] = w;
 		winv[e] = w;
@@ -1129,7 +1138,7 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, 
 		dvec[lane] = (dbits >> lane) & 1;
 	__syncthreads();
 	/* c = -(winv * spliced), vtAvd = -vtAv on the selected columns (:462-475), canonical */
-	for (int e = lane; e < nn; e += 64) {
+	for (int e = lane; e < nn; e += T) {
 		const int i = e / n, j = e % n;
 		const bool dj = (dbits >> j) & 1;
 		const u64 *sp = dj ? vtAAv : vtAv;
@@ -1325,12 +1334,14 @@ hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int 
 		return hipGetLastError();
 	}
 	const size_t lds = ((size_t)2 * c.n * c.n + 2 * c.n) * sizeof(u64);
+	/* one thread per matrix entry up to a full workgroup: every elimination step is then one pass (n = 64: four) */
+	const int threads = G * G > 1024 ? 1024 : (G * G < 64 ? 64 : G * G);
 #define SEMI(MM)                                                                                                   \
 	do {                                                                                                       \
 		if (lds > 48 * 1024)                                                                               \
 			hipFuncSetAttribute((const void *)k_semi_inverse<MM>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
 					    (int)lds);                                                             \
-		hipLaunchKernelGGL((k_semi_inverse<MM>), dim3(1), dim3(64), lds, s, small, ctl, c.n, G, c.m, in_loop); \
+		hipLaunchKernelGGL((k_semi_inverse<MM>), dim3(1), dim3(threads), lds, s, small, ctl, c.n, G, c.m, in_loop); \
 	} while (0)
 	if (c.mers == 61)
 		SEMI(61);
