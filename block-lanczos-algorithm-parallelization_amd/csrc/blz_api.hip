@@ -125,6 +125,7 @@ struct blz_ctx {
 	bool reorder = true;		/* BLZ_NO_REORDER=1 keeps the file's numbering */
 	bool pack = true;		/* BLZ_NO_PACK=1 keeps col_idx and val as two arrays */
 	bool fuse_dot = true;		/* BLZ_NO_FUSE=1 keeps block_dot as its own kernel (A/B measurements) */
+	int un = 0;			/* the caller's block width; cfg.n is the width in HBM (below) */
 	bool use_graph = false;		/* BLZ_GRAPH=1: single-GPU iterations are replayed from a captured hipGraph */
 	hipGraphExec_t iter_graph = nullptr;
 	bool external_exchange = false;
@@ -212,7 +213,19 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	blz_ctx *c = new blz_ctx();
 	c->device = device;
 	c->prime = prime;
+	/* Blocks live in HBM with the width rounded up to a power of two, the extra columns zero: block rows are then
+	 * aligned to the 128-byte lines the gathers fetch, and every width runs the specialised kernels of the next
+	 * power of two.  Zero columns stay zero through every step (they are never pivots, their coefficients are zero),
+	 * so the caller's n columns are the reference's.  BLZ_NO_PAD=1 keeps the exact width (generic kernels). */
+	c->un = n;
 	c->cfg.n = n;
+	{
+		const char *npad = getenv("BLZ_NO_PAD");
+		if (!(npad && npad[0] == '1'))
+			while (c->cfg.n & (c->cfg.n - 1))
+				c->cfg.n++;
+	}
+	const int np_ = c->cfg.n;
 	c->cfg.word = prime < (1ull << 32) ? 4 : 8;
 	c->cfg.mers = modp_mersenne(prime);
 	c->cfg.m = make_modp(prime);
@@ -237,12 +250,12 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	HIPCHK(hipEventCreateWithFlags(&c->ev_prod, hipEventDisableTiming));
 	HIPCHK(hipEventCreate(&c->ev0));
 	HIPCHK(hipEventCreate(&c->ev1));
-	HIPCHK(hipMalloc(&c->small, small_words(n) * sizeof(u64)));
-	HIPCHK(hipMemset(c->small, 0, small_words(n) * sizeof(u64)));
+	HIPCHK(hipMalloc(&c->small, small_words(np_) * sizeof(u64)));
+	HIPCHK(hipMemset(c->small, 0, small_words(np_) * sizeof(u64)));
 	/* partial rows of the inner products: the fused path (n <= 8) needs room for the streaming kernel plus the
 	 * outlier launches; the stand-alone kernel keeps the grid it was tuned with */
-	c->max_dot_blocks = c->cfg.num_cu * (n <= 8 ? 16 : 8);
-	HIPCHK(hipMalloc(&c->partial, (size_t)c->max_dot_blocks * 2 * n * n * sizeof(u64)));
+	c->max_dot_blocks = c->cfg.num_cu * (np_ <= 8 ? 16 : 8);
+	HIPCHK(hipMalloc(&c->partial, (size_t)c->max_dot_blocks * 2 * np_ * np_ * sizeof(u64)));
 	HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
 	*out = c;
@@ -590,6 +603,30 @@ static int get_words(blz_ctx *c, uint64_t *dst, const void *src, int64_t words)
 	return BLZ_OK;
 }
 
+/* `rows` block rows: host rows are c->un words wide, device rows c->cfg.n (zero-padded) */
+static int put_rows(blz_ctx *c, void *dst, const uint64_t *src, int64_t rows)
+{
+	const int un = c->un, np = c->cfg.n;
+	if (un == np || rows <= 0)
+		return put_words(c, dst, src, rows * np);
+	std::vector<uint64_t> wide((size_t)rows * np, 0);
+	for (int64_t r = 0; r < rows; r++)
+		memcpy(wide.data() + (size_t)r * np, src + (size_t)r * un, (size_t)un * sizeof(uint64_t));
+	return put_words(c, dst, wide.data(), rows * np);
+}
+
+static int get_rows(blz_ctx *c, uint64_t *dst, const void *src, int64_t rows)
+{
+	const int un = c->un, np = c->cfg.n;
+	if (un == np || rows <= 0)
+		return get_words(c, dst, src, rows * np);
+	std::vector<uint64_t> wide((size_t)rows * np);
+	int rc = get_words(c, wide.data(), src, rows * np);
+	for (int64_t r = 0; r < rows && rc == BLZ_OK; r++)
+		memcpy(dst + (size_t)r * un, wide.data() + (size_t)r * np, (size_t)un * sizeof(uint64_t));
+	return rc;
+}
+
 #define NEED_MATRIX(c)                                                                  \
 	do {                                                                            \
 		if (!(c) || !(c)->have_matrix)                                          \
@@ -600,7 +637,7 @@ static int get_words(blz_ctx *c, uint64_t *dst, const void *src, int64_t words)
 /* host block in ORIGINAL numbering -> one contiguous array in the solver's numbering (and back) */
 static void to_solver_order(const blz_ctx *c, int sd, const uint64_t *host, uint64_t *out)
 {
-	const int n = c->cfg.n;
+	const int n = c->un;
 	const int64_t rows = c->glob_rows[sd];
 	if (c->perm[sd].empty()) {
 		memcpy(out, host, (size_t)rows * n * sizeof(uint64_t));
@@ -616,7 +653,7 @@ extern "C" int blz_set_block(blz_ctx *c, int block, const uint64_t *host)
 	if (block < 0 || block > 3 || !host)
 		return blz_fail(BLZ_EINVAL, "blz_set_block: bad argument");
 	HIPCHK(hipStreamSynchronize(c->stream));
-	const int sd = side_of(block), n = c->cfg.n;
+	const int sd = side_of(block), n = c->un, np = c->cfg.n;
 	std::vector<uint64_t> tmp;
 	const uint64_t *src = host;
 	if (!c->perm[sd].empty()) {
@@ -626,7 +663,7 @@ extern "C" int blz_set_block(blz_ctx *c, int block, const uint64_t *host)
 	}
 	HIPCHK(hipStreamSynchronize(c->xstream));
 	/* this rank's rows */
-	int rc = put_words(c, c->slab[block], src + c->first[sd] * n, c->count[sd] * n);
+	int rc = put_rows(c, c->slab[block], src + c->first[sd] * n, c->count[sd]);
 	if (rc != BLZ_OK || c->nranks == 1)
 		return rc;
 	/* and, with several ranks, the whole gathered operand (an all-gather done by the caller): piece k of rank g
@@ -639,8 +676,8 @@ extern "C" int blz_set_block(blz_ctx *c, int block, const uint64_t *host)
 			const int64_t q0 = (int64_t)k * piece, q1 = std::min<int64_t>(q0 + piece, cnt);
 			if (q1 <= q0)
 				break;
-			char *dst = (char *)c->gath[sd] + (size_t)(((int64_t)k * c->nranks + g) * piece) * n * c->cfg.word;
-			rc = put_words(c, dst, src + (b0 + q0) * n, (q1 - q0) * n);
+			char *dst = (char *)c->gath[sd] + (size_t)(((int64_t)k * c->nranks + g) * piece) * np * c->cfg.word;
+			rc = put_rows(c, dst, src + (b0 + q0) * n, q1 - q0);
 			if (rc != BLZ_OK)
 				return rc;
 		}
@@ -656,11 +693,11 @@ extern "C" int blz_get_block(blz_ctx *c, int block, uint64_t *host)
 		return blz_fail(BLZ_EINVAL, "blz_get_block: bad argument");
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipStreamSynchronize(c->xstream));
-	const int sd = side_of(block), n = c->cfg.n;
+	const int sd = side_of(block), n = c->un;
 	if (c->perm[sd].empty())
-		return get_words(c, host + c->first[sd] * n, slab_ptr(c, block), c->count[sd] * n);
+		return get_rows(c, host + c->first[sd] * n, slab_ptr(c, block), c->count[sd]);
 	std::vector<uint64_t> tmp((size_t)std::max<int64_t>(c->count[sd], 1) * n);
-	int rc = get_words(c, tmp.data(), slab_ptr(c, block), c->count[sd] * n);
+	int rc = get_rows(c, tmp.data(), slab_ptr(c, block), c->count[sd]);
 	if (rc != BLZ_OK)
 		return rc;
 	for (int64_t q = 0; q < c->count[sd]; q++)
@@ -705,7 +742,14 @@ extern "C" int blz_set_small(blz_ctx *c, int which, const uint64_t *host)
 	if (off < 0)
 		return blz_fail(BLZ_EINVAL, "blz_set_small: unknown operand %d", which);
 	HIPCHK(hipStreamSynchronize(c->stream));
-	HIPCHK(hipMemcpy(c->small + off, host, (size_t)words * sizeof(u64), hipMemcpyHostToDevice));
+	std::vector<u64> dev((size_t)words, 0);		/* the caller's un x un (or un) words inside the padded operand */
+	const int un = c->un, np = c->cfg.n;
+	if (which == BLZ_D)
+		memcpy(dev.data(), host, (size_t)un * sizeof(u64));
+	else
+		for (int i = 0; i < un; i++)
+			memcpy(dev.data() + (size_t)i * np, host + (size_t)i * un, (size_t)un * sizeof(u64));
+	HIPCHK(hipMemcpy(c->small + off, dev.data(), (size_t)words * sizeof(u64), hipMemcpyHostToDevice));
 	return BLZ_OK;
 }
 
@@ -718,7 +762,14 @@ extern "C" int blz_get_small(blz_ctx *c, int which, uint64_t *host)
 	if (off < 0)
 		return blz_fail(BLZ_EINVAL, "blz_get_small: unknown operand %d", which);
 	HIPCHK(hipStreamSynchronize(c->stream));
-	HIPCHK(hipMemcpy(host, c->small + off, (size_t)words * sizeof(u64), hipMemcpyDeviceToHost));
+	std::vector<u64> dev((size_t)words);
+	HIPCHK(hipMemcpy(dev.data(), c->small + off, (size_t)words * sizeof(u64), hipMemcpyDeviceToHost));
+	const int un = c->un, np = c->cfg.n;
+	if (which == BLZ_D)
+		memcpy(host, dev.data(), (size_t)un * sizeof(u64));
+	else
+		for (int i = 0; i < un; i++)
+			memcpy(host + (size_t)i * un, dev.data() + (size_t)i * np, (size_t)un * sizeof(u64));
 	return BLZ_OK;
 }
 
@@ -733,7 +784,7 @@ extern "C" int blz_init_v(blz_ctx *c)
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
 	c->host_ctl = DevCtl{};
 	/* :624-625: one sequential stream over the whole block in ORIGINAL row order; a rank keeps the rows it owns. */
-	const int n = c->cfg.n;
+	const int n = c->un;
 	const int64_t keep = c->count[0] * n, lo = c->first[0], hi = c->first[0] + c->count[0];
 	std::vector<uint64_t> mine((size_t)std::max<int64_t>(keep, 1));
 	uint64_t s[4];
@@ -748,7 +799,7 @@ extern "C" int blz_init_v(blz_ctx *c)
 				(void)blz_rng_next(s);
 		}
 	}
-	return put_words(c, slab_ptr(c, BLZ_V), mine.data(), keep);
+	return put_rows(c, slab_ptr(c, BLZ_V), mine.data(), c->count[0]);
 }
 
 /* ---- exchange steps (RCCL over xGMI).  No-ops on a single rank. ---- */
@@ -873,15 +924,17 @@ extern "C" int blz_block_dot(blz_ctx *c, uint64_t *vtAv, uint64_t *vtAAv)
 	if (rc != BLZ_OK)
 		return rc;
 	HIPCHK(hipStreamSynchronize(c->stream));
-	const int nn = c->cfg.n * c->cfg.n;
+	const int np = c->cfg.n, un = c->un, nn = np * np;
 	std::vector<u64> h((size_t)2 * nn);
 	HIPCHK(hipMemcpy(h.data(), c->small, (size_t)2 * nn * sizeof(u64), hipMemcpyDeviceToHost));
 	for (int e = 0; e < 2 * nn; e++)
 		h[(size_t)e] %= c->prime;	/* multi-rank sums are reduced by the next kernel; mirror it here */
-	if (vtAv)
-		memcpy(vtAv, h.data(), (size_t)nn * sizeof(u64));
-	if (vtAAv)
-		memcpy(vtAAv, h.data() + nn, (size_t)nn * sizeof(u64));
+	for (int i = 0; i < un; i++) {
+		if (vtAv)
+			memcpy(vtAv + (size_t)i * un, h.data() + (size_t)i * np, (size_t)un * sizeof(u64));
+		if (vtAAv)
+			memcpy(vtAAv + (size_t)i * un, h.data() + nn + (size_t)i * np, (size_t)un * sizeof(u64));
+	}
 	return BLZ_OK;
 }
 

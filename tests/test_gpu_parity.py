@@ -126,8 +126,12 @@ def test_full_solve_against_oracle_all_prime_classes(p, name, n, right):
     assert np.array_equal(got["p"], want["p"])
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 8, 11, 16, 24, 32, 64])
-def test_every_block_width(n):
+@pytest.mark.parametrize("pad", ["padded", "exact"])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 8, 11, 16, 24, 32, 48, 64])
+def test_every_block_width(monkeypatch, n, pad):
+    """Blocks live in HBM with their width rounded up to a power of two (zero columns), so every width runs the
+    specialised kernels; BLZ_NO_PAD=1 keeps the exact width and the generic kernels.  Same words either way."""
+    monkeypatch.setenv("BLZ_NO_PAD", "1" if pad == "exact" else "0")
     p = P61 if n % 2 else 1073741789
     M, Mo = load_both("rand300x200", p)
     its = 6 if n <= 32 else 3        # rank(M M^T) <= 200: wider blocks exhaust the Krylov space earlier
