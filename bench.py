@@ -312,6 +312,32 @@ def main():
             except Exception as exc:   # the reference is a reported extra, never a reason to lose the bench line
                 out["cpu_reference"] = {"error": repr(exc)}
 
+    # ---- several ranks (or the exchange code forced on one): the sharded run must hold the same block as one GPU
+    # solving the whole system.  Every rank sums the words of its slab of v; rank 0 repeats the same number of
+    # iterations on a plain single-GPU context (tens of milliseconds) and compares the totals mod 2^64.
+    if dist is not None:
+        iters_done = ctx.iterations
+        mine = int(ctx.get_block(blz.V).sum(dtype=np.uint64))          # rows of other ranks are left at zero
+        tot = torch.tensor([mine & 0x7FFFFFFF, (mine >> 31) & 0x7FFFFFFF, mine >> 62], dtype=torch.int64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        its_t = torch.tensor([iters_done], dtype=torch.int64)
+        dist.all_reduce(its_t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            total = (int(tot[0]) + (int(tot[1]) << 31) + (int(tot[2]) << 62)) & ((1 << 64) - 1)
+            saved = {k_: os.environ.pop(k_) for k_ in ("BLZ_FORCE_COMM",) if k_ in os.environ}
+            one = blz.Context(p, n, device=local_rank)
+            one.set_matrix(M, right)
+            one.init_v()
+            one.iterate(iters_done)
+            want = int(one.get_block(blz.V).sum(dtype=np.uint64))
+            same = bool(want == total and one.iterations == iters_done == int(its_t[0]))
+            one.close()
+            os.environ.update(saved)
+            out["sharded_equals_single_gpu"] = {"equal": same, "iterations": iters_done,
+                                                "check": "sum of the words of v mod 2^64, all ranks, vs one GPU on the whole matrix"}
+            if not same:
+                print("bench.py: WARNING the sharded run and the single-GPU run disagree", file=sys.stderr)
+
     ctx.close()
     if rank == 0:
         sys.stdout.flush()
