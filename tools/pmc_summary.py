@@ -7,7 +7,7 @@ root, want = sys.argv[1], sys.argv[2:]
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:90]
         if want and not any(w in k for w in want):
             continue
         a = acc[k][r["Counter_Name"]]
