@@ -234,6 +234,10 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	if (const char *bp = getenv("BLZ_SPMV_BLOCKS_PER_CU"))
 		if (atoi(bp) >= 1 && atoi(bp) <= 64)
 			c->cfg.spmv_blocks_per_cu = atoi(bp);
+	{
+		const char *ns = getenv("BLZ_NO_STAGE");
+		c->cfg.staged = !(ns && ns[0] == '1');
+	}
 	const char *np = getenv("BLZ_NO_PACK");
 	c->pack = !(np && np[0] == '1');
 	const char *nr = getenv("BLZ_NO_REORDER");
@@ -311,7 +315,8 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
 	D.nnz = H.nnz;
 	HIPCHK(hipMalloc(&D.row_ptr, (size_t)(H.rows + 1) * sizeof(u32)));
 	HIPCHK(hipMemcpy(D.row_ptr, H.row_ptr, (size_t)(H.rows + 1) * sizeof(u32), hipMemcpyHostToDevice));
-	HIPCHK(hipMalloc(&D.col_idx, (size_t)(H.nnz ? H.nnz : 1) * sizeof(int)));
+	HIPCHK(hipMalloc(&D.col_idx, (size_t)(H.nnz + BLZ_STREAM_PAD) * sizeof(int)));
+	HIPCHK(hipMemset(D.col_idx + H.nnz, 0, BLZ_STREAM_PAD * sizeof(int)));
 	/* Packed stream: when the slab has at most 256 distinct values and fewer than 2^24 columns, each entry
 	 * travels as ONE u32 (column | palette index << 24) instead of two; the SpMV is bound by the number of
 	 * fabric requests, and this halves those of the matrix stream.  BLZ_NO_PACK=1 keeps the plain arrays. */
@@ -346,7 +351,8 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
 	if (!packed) {
 		HIPCHK(hipMemcpy(D.col_idx, H.col_idx, (size_t)H.nnz * sizeof(int), hipMemcpyHostToDevice));
 		if (H.val) {
-			HIPCHK(hipMalloc(&D.val, (size_t)(H.nnz ? H.nnz : 1) * sizeof(u32)));
+			HIPCHK(hipMalloc(&D.val, (size_t)(H.nnz + BLZ_STREAM_PAD) * sizeof(u32)));
+			HIPCHK(hipMemset(D.val + H.nnz, 0, BLZ_STREAM_PAD * sizeof(u32)));
 			HIPCHK(hipMemcpy(D.val, H.val, (size_t)H.nnz * sizeof(u32), hipMemcpyHostToDevice));
 		}
 	}
@@ -401,6 +407,7 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
 		HIPCHK(hipMemcpy(D.heavy_multi, multi.data(), multi.size() * sizeof(HeavyRow), hipMemcpyHostToDevice));
 		HIPCHK(hipMalloc(&D.heavy_scratch, heavy.size() * 64 * 2 * sizeof(u64)));
 	}
+	spmv_plan_staged(c->cfg, H.row_ptr, D);
 	return BLZ_OK;
 }
 

@@ -33,7 +33,18 @@ struct DevCsr {
 	double kept_mean = -1.0;	/* mean length of the rows the streaming kernel keeps (< 0: nnz / rows) */
 	u32 heavy_thr = 0xFFFFFFFFu;
 	bool uneven = false;		/* row lengths vary a lot (std > mean/2): the SpMV wants more resident waves */
+	/* plan of the LDS-staged streaming kernel (k_spmv_staged), made at upload by spmv_plan_staged() */
+	bool st_ok = false;		/* false: the slab runs k_spmv / k_spmv_dot */
+	int st_rpg = 0;			/* rows per lane group per tile: a tile is (64/G) * st_rpg consecutive rows */
+	int st_capw = 0;		/* staging window per wavefront and buffer, entries */
+	int st_per_cu = 0;		/* resident workgroups per CU the grid is sized for */
+	int st_ns = 1;			/* streams staged: col_idx (+ val when it is a separate array) */
+	int st_interleave = 0;		/* 1: tiles round-robin over the whole grid instead of per-XCD ranges */
+	long long st_tiles[9] = { 0 };	/* XCD x takes tiles [st_tiles[x], st_tiles[x+1]): contiguous, nnz-balanced */
 };
+
+/* col_idx / val of a slab are allocated with this many spare entries: the staged kernel copies whole 16-byte chunks */
+#define BLZ_STREAM_PAD 16
 
 /* Control words shared by all kernels of a context (device memory). */
 struct DevCtl {
@@ -50,7 +61,12 @@ struct KernelCfg {
 	ModP m;
 	int num_cu;
 	int spmv_blocks_per_cu;	/* grid of the persistent SpMV = num_cu * this (BLZ_SPMV_BLOCKS_PER_CU overrides) */
+	int staged;		/* 1: slabs with a plan run k_spmv_staged; BLZ_NO_STAGE=1 keeps the round-1 kernels (A/B) */
 };
+
+/* fills the st_* fields of D from the host copy of its row pointers (D.rows, D.nnz, D.val, D.palette, D.kept_mean,
+ * D.uneven must be set) */
+void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D);
 
 /* rows of a slab with more entries than this get a workgroup each (DevCsr::heavy) */
 u32 spmv_heavy_threshold(const KernelCfg &c, int64_t rows, int64_t nnz);

@@ -306,12 +306,19 @@ u32 spmv_heavy_threshold(const KernelCfg &c, int64_t rows, int64_t nnz)
 	return base << spmv_split_log2(c, rows, nnz);
 }
 
+/* the same product with the matrix stream staged through LDS (further down: it shares DotState with k_spmv_dot) */
+template <typename W, int MERS, bool DOT>
+static hipError_t staged_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum,
+				  u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s);
+
 template <typename W, int MERS>
 static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, int accum, const DevCtl *ctl,
 				hipStream_t s)
 {
 	if (A.rows == 0)
 		return hipSuccess;
+	if (A.st_ok && c.staged)
+		return staged_dispatch<W, MERS, false>(c, A, X, Y, (const W *)nullptr, accum, (u64 *)nullptr, 0, (int *)nullptr, ctl, s);
 	int G = 1;
 	while (G < c.n)
 		G <<= 1;
@@ -816,6 +823,8 @@ template <typename W, int MERS>
 static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum,
 				    u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
 {
+	if (A.st_ok && c.staged)
+		return staged_dispatch<W, MERS, true>(c, A, X, Y, Vd, accum, partial, max_blocks, nblocks, ctl, s);
 	const long long gpb = BLOCK / c.n;
 	long long blocks = (A.rows + gpb - 1) / gpb;
 	/* the accumulators cost registers: 4 resident blocks per CU at n = 8, so size the grid for that */
@@ -859,6 +868,375 @@ hipError_t launch_spmv_dot(const KernelCfg &c, const DevCsr &A, const void *X, v
 				    : spmv_dot_dispatch<u32, 0>(c, A, (const u32 *)X, (u32 *)Y, (const u32 *)Vd, accum, partial, max_blocks, nblocks, ctl, s);
 	return c.mers == 61 ? spmv_dot_dispatch<u64, 61>(c, A, (const u64 *)X, (u64 *)Y, (const u64 *)Vd, accum, partial, max_blocks, nblocks, ctl, s)
 			    : spmv_dot_dispatch<u64, 0>(c, A, (const u64 *)X, (u64 *)Y, (const u64 *)Vd, accum, partial, max_blocks, nblocks, ctl, s);
+}
+
+/* ------------------------------------------------------- SpMV, matrix stream staged through LDS (round 2) */
+
+/*
+ * Same product as k_spmv / k_spmv_dot (sequential/lanczos_modp.c:266-287), three things changed:
+ *
+ * 1. The matrix stream goes through LDS.  k_spmv reads row_ptr / col_idx with 4-byte loads that are uniform inside
+ *    a lane group: every 128-byte line of the stream is requested from L2 about six times (the gathers evict it from
+ *    the 32 KB L1 between uses; profiles/r01_v6_gl7d19_pmc_l2_fabric.txt: 7.5 M stream requests per launch where
+ *    1.2 M lines would do).  Here a wavefront owns a TILE of TR = (64/G) * rpg consecutive rows; the tile's entries
+ *    are one contiguous piece of col_idx (and val), copied into the wavefront's LDS buffer with 16-byte-per-lane
+ *    LDS-DMA loads (global_load_lds_dwordx4: 1 KB per instruction, no VGPRs), one tile ahead of the gathers, so each
+ *    line of the stream crosses L2 -> CU once.  The row pointers of a tile are one coalesced load (lane i holds
+ *    rp[r0 + i]) fetched two tiles ahead; lanes read them from each other.
+ * 2. Tiles are dealt to XCDs in contiguous, nnz-balanced ranges (XcdTiles): blocks b and b + 8 share an XCD
+ *    (observed round-robin placement, MI355X_MICROARCH.md -- speed only, any placement computes every tile once), so
+ *    an XCD's 4 MB L2 sees one eighth of the rows instead of an interleaved sample of all of them; on matrices whose
+ *    rows have local column supports each L2 then caches a different part of X.
+ * 3. Row tails are predicated batches, not one dependent gather per left-over entry.
+ *
+ * A row whose entries do not all fit the staged window (tiles of unusually long rows) takes the k_spmv path from
+ * global memory; rows above the outlier threshold are left to k_spmv_wave / k_spmv_heavy as before.
+ */
+enum { V_ONES = 0, V_PACKED = 1, V_ARRAY = 2 };
+
+struct XcdTiles {
+	long long begin[9];
+	int interleave;		/* 1: tiles dealt round-robin over all wavefronts of the grid (no XCD ranges) */
+};
+
+template <typename W, int VALS, int U>
+MODP_DEV void staged_accumulate(Acc &acc, u32 i, u32 i1, const u32 *sci, const u32 *sva, const u32 *spal,
+				const W *__restrict__ X, int stride, int xl)
+{
+	/* every slot of a batch reads LDS and gathers unconditionally (a left-over slot re-reads the row's last entry:
+	 * same LDS word, same line of X) and is switched off by a zero multiplier: no branches inside the batch */
+	const u32 last = i1 - 1;
+	for (; i < i1; i += U) {
+		u32 c[U];
+		u32 a[U];
+		W x[U];
+#pragma unroll
+		for (int j = 0; j < U; j++) {
+			const u32 at = i + j < i1 ? i + j : last;
+			c[j] = sci[at];
+			if (VALS == V_ARRAY)
+				a[j] = sva[at];
+		}
+#pragma unroll
+		for (int j = 0; j < U; j++) {
+			x[j] = X[(size_t)(VALS == V_PACKED ? (c[j] & 0xFFFFFFu) : c[j]) * stride + xl];
+			if (VALS == V_PACKED)
+				a[j] = spal[c[j] >> 24];
+		}
+#pragma unroll
+		for (int j = 0; j < U; j++) {
+			const bool live = i + j < i1;
+			if (VALS == V_ONES)
+				acc_add(acc, live ? (u64)x[j] : 0ull);
+			else
+				acc_mac32(acc, live ? a[j] : 0u, x[j]);
+		}
+	}
+}
+
+template <typename W, int G, int MERS, bool DOT, int VALS, int U>
+__global__ void __launch_bounds__(BLOCK, (DOT && G >= 8) ? 4 : 1)	/* the fused form at n = 8 must keep 4 workgroups per CU (<= 128 VGPRs) */
+k_spmv_staged(const u32 *__restrict__ rp, const u32 *__restrict__ ci, const u32 *__restrict__ va,
+	      const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
+	      long long rows, int n, int rpg, int capw, int accum, u32 heavy, ModP m, u64 *__restrict__ partial,
+	      XcdTiles xt, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int GPW = 64 / G, NS = VALS == V_ARRAY ? 2 : 1, WAVES = BLOCK / 64, NT = DOT ? G : 1;
+	using DS = DotState<typename std::conditional<sizeof(W) == 4, AccS, Acc>::type, MERS, NT>;
+	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
+	__shared__ u32 spal_store[BLOCK];
+	extern __shared__ __attribute__((aligned(16))) u32 stage[];	/* [wave][2 buffers][NS streams][capw] */
+	if (VALS == V_PACKED)
+		spal_store[threadIdx.x] = pal[threadIdx.x];
+	__syncthreads();
+	const int t = threadIdx.x, wl = t & 63, wave = t >> 6, lane = wl & (G - 1), grp = wl / G;
+	const int xl = lane < n ? lane : 0, gbase = wl - lane;
+	u32 *const mine = stage + (size_t)wave * 2 * NS * capw;
+	const int TR = GPW * rpg;
+	const int xcd = blockIdx.x & 7;
+	const long long nwv = xt.interleave ? (long long)gridDim.x * WAVES : (long long)(gridDim.x >> 3) * WAVES;
+	long long tile = xt.interleave ? (long long)blockIdx.x * WAVES + wave
+				       : xt.begin[xcd] + (long long)(blockIdx.x >> 3) * WAVES + wave;
+	const long long tile_end = xt.interleave ? xt.begin[8] : xt.begin[xcd + 1];
+	DS ds;
+	if (DOT)
+		ds.init();
+
+	/* row pointers of a tile: lane i holds rp[r0 + i] (clamped), `re` = rp[r0 + TR] */
+	auto load_rp = [&](long long tl, u32 &rv, u32 &re) {
+		const long long r0 = tl * TR;
+		long long a = r0 + wl, b = r0 + TR;
+		a = a > rows ? rows : a;
+		b = b > rows ? rows : b;
+		rv = rp[a];
+		re = rp[b];
+	};
+	/* copy the tile's piece of the stream(s) into buffer `buf`: entries [K0, K0 + capw) with K0 = rp[r0] & ~3 */
+	auto stage_tile = [&](u32 rv, u32 re, int buf) {
+		const u32 klo = (u32)__shfl((int)rv, 0, 64), K0 = klo & ~3u;
+		u32 cnt = re - K0;
+		cnt = cnt > (u32)capw ? (u32)capw : cnt;
+		const u32 nch = (cnt + 3u) >> 2;
+		u32 *dst = mine + (size_t)buf * NS * capw;
+		for (u32 c = 0; c < nch; c += 64) {
+			if (c + (u32)wl < nch) {
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ci + (size_t)K0 + 4 * (size_t)(c + wl)),
+								 (__attribute__((address_space(3))) void *)(dst + 4 * c), 16, 0, 0);
+				if (VALS == V_ARRAY)
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(va + (size_t)K0 + 4 * (size_t)(c + wl)),
+									 (__attribute__((address_space(3))) void *)(dst + capw + 4 * c), 16, 0, 0);
+			}
+		}
+	};
+
+	u32 rv0 = 0, re0 = 0, rv1 = 0, re1 = 0;
+	if (tile < tile_end) {
+		load_rp(tile, rv0, re0);
+		stage_tile(rv0, re0, 0);
+		if (tile + nwv < tile_end)
+			load_rp(tile + nwv, rv1, re1);
+	}
+	/* The store of a finished row is issued one row late (after the next row's sums are complete), so that at the top
+	 * of a tile the youngest vector-memory operations of the wavefront are gathers it has already consumed: memory
+	 * operations retire in issue order, and the wait for the tile's stream then costs nothing -- with the store issued
+	 * last it exposed the full store latency once per tile (measured: +3..5 % on the GL7d19 shape). */
+	W *pend_at = nullptr;
+	u64 pend_y = 0;
+	int buf = 0;
+	for (; tile < tile_end; tile += nwv, buf ^= 1) {
+		/* everything this wavefront has issued so far has landed: this tile's stream and the next tile's row pointers */
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		u32 rv2 = 0, re2 = 0;
+		if (tile + nwv < tile_end) {
+			stage_tile(rv1, re1, buf ^ 1);
+			if (tile + 2 * nwv < tile_end)
+				load_rp(tile + 2 * nwv, rv2, re2);
+		}
+		asm volatile("" ::: "memory");
+		const long long r0 = tile * TR;
+		const u32 K0 = (u32)__shfl((int)rv0, 0, 64) & ~3u;
+		const u32 *sci = mine + (size_t)buf * NS * capw, *sva = sci + capw;
+		for (int j = 0; j < rpg; j++) {
+			const int q = j * GPW + grp;
+			const long long r = r0 + q;
+			const u32 k = (u32)__shfl((int)rv0, q, 64);
+			const u32 enext = (u32)__shfl((int)rv0, (q + 1) & 63, 64);
+			const u32 e = q + 1 < 64 ? enext : re0;
+			if (r < rows && e - k <= heavy) {
+				Acc acc;
+				acc_zero(acc);
+				u64 vi = 0;
+				if (DOT)
+					vi = Vd[(size_t)r * NT + lane];
+				if (e - K0 <= (u32)capw)
+					staged_accumulate<W, VALS, U>(acc, k - K0, e - K0, sci, sva, spal_store, X, n, xl);
+				else
+					spmv_accumulate<W>(acc, k, e, (const int *)ci, VALS == V_ARRAY ? va : nullptr,
+							   VALS == V_PACKED ? spal_store : nullptr, X, n, xl);
+				if (lane < n) {
+					if (accum)
+						acc_add(acc, Y[(size_t)r * n + lane]);
+					const u64 y = acc_reduce<MERS>(acc, m);
+					if (pend_at)
+						*pend_at = (W)pend_y;
+					pend_at = Y + (size_t)r * n + lane;
+					pend_y = y;
+					if (DOT)
+						ds.row(vi, y, lane, gbase, m);
+				}
+			}
+		}
+		rv0 = rv1;
+		re0 = re1;
+		rv1 = rv2;
+		re1 = re2;
+	}
+	if (pend_at)
+		*pend_at = (W)pend_y;
+	if (DOT)
+		ds.finish(red, partial, m, (int)blockIdx.x);
+}
+
+/* Host side of the plan, made once per slab at upload (blz_api.hip): tile height, staging window, grid density and the
+ * nnz-balanced tile ranges of the eight XCDs. */
+void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D)
+{
+	D.st_ok = false;
+	if (D.rows <= 0 || D.nnz <= 0)
+		return;
+	int G = 1;
+	while (G < c.n)
+		G <<= 1;
+	if (spmv_split_log2(c, D.rows, D.nnz) != 0)	/* few long rows shared by adjacent groups: k_spmv */
+		return;
+	{
+		/* Measured on MI355X (gpurun_out r2a..r2g, profiles/r02_staged_*): staging pays where the stream is a large
+		 * part of the row's work or rows span several lines of it -- relat9 shape, rows of 3 entries: 711 -> 668 us,
+		 * its transpose, rows of 71: 751 -> 727 us -- and costs 2-4 % on rows of ~20 entries (GL7d19 shape: 654 ->
+		 * 670 us at every tile height, window, grid density and batch depth tried), where k_spmv's per-row loads
+		 * already hit L1.  BLZ_STAGE_ALWAYS=1 stages every slab (PMC comparisons). */
+		const double a = D.kept_mean >= 0.0 ? D.kept_mean : (double)D.nnz / (double)D.rows;
+		const char *e = getenv("BLZ_STAGE_ALWAYS");
+		if (!(e && e[0] == '1') && a >= 12.0 && a < 48.0)
+			return;
+	}
+	const int GPW = 64 / G, NS = (D.val && !D.palette) ? 2 : 1;
+	const double avg = D.kept_mean >= 0.0 ? D.kept_mean : (double)D.nnz / (double)D.rows;
+	int per_cu = c.spmv_blocks_per_cu > 0 ? c.spmv_blocks_per_cu : ((avg >= 12.0 && G < 16) ? (D.uneven ? 6 : 4) : 8);
+	/* LDS: 4 wavefronts x 2 buffers x capw entries x 4 B per block (x NS streams); 160 KB per CU */
+	int capw = (per_cu <= 4 ? 1024 : 512) / NS;
+	if (const char *e = getenv("BLZ_STAGE_CAPW"))
+		if (atoi(e) >= 64 && atoi(e) <= 4096)
+			capw = atoi(e) & ~3;
+	while ((long long)per_cu * (BLOCK / 64) * 2 * NS * capw * 4 > 150 * 1024 && per_cu > 1)
+		per_cu--;
+	int rpg = (int)(0.6 * capw / (GPW * (avg > 1.0 ? avg : 1.0)));
+	if (const char *e = getenv("BLZ_STAGE_RPG"))
+		if (atoi(e) >= 1)
+			rpg = atoi(e);
+	if (rpg < 1) {
+		if (GPW * avg * 1.25 > capw)	/* a tile of one row per group does not fit the window: nothing to stage */
+			return;
+		rpg = 1;
+	}
+	if (rpg > 64 / GPW)
+		rpg = 64 / GPW;
+	const long long TR = (long long)GPW * rpg, nt = (D.rows + TR - 1) / TR;
+	D.st_rpg = rpg;
+	D.st_capw = capw;
+	D.st_per_cu = per_cu;
+	D.st_ns = NS;
+	D.st_tiles[0] = 0;
+	for (int x = 1; x < 8; x++) {
+		const double target = (double)D.nnz * x / 8.0;
+		long long lo = D.st_tiles[x - 1], hi = nt;
+		while (lo < hi) {
+			const long long mid = (lo + hi) / 2, r = mid * TR < D.rows ? mid * TR : D.rows;
+			if ((double)row_ptr[r] < target)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		D.st_tiles[x] = lo;
+	}
+	D.st_tiles[8] = nt;
+	{
+		const char *e = getenv("BLZ_STAGE_INTERLEAVE");	/* experiments: 1 = no XCD ranges */
+		D.st_interleave = e && e[0] == '1';
+	}
+	D.st_ok = true;
+}
+
+template <typename W, int MERS, bool DOT, int G, int VALS>
+static void staged_launch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum, u64 *partial,
+			  long long blocks, const DevCtl *ctl, hipStream_t s)
+{
+	XcdTiles xt;
+	for (int x = 0; x < 9; x++)
+		xt.begin[x] = A.st_tiles[x];
+	xt.interleave = A.st_interleave;
+	const size_t lds = (size_t)(BLOCK / 64) * 2 * A.st_ns * A.st_capw * sizeof(u32);
+	/* gathers in flight per lane: 8 where a wavefront holds few lane groups (G >= 16) or the registers allow (the
+	 * plain form at G = 8), else 4; BLZ_STAGE_U overrides between the two where both exist */
+	bool deep = G >= 16 || (G == 8 && !DOT);
+	if (const char *e = getenv("BLZ_STAGE_U"))
+		deep = atoi(e) >= 8;
+#define STAGED_GO(UU)                                                                                                   \
+	hipLaunchKernelGGL((k_spmv_staged<W, G, MERS, DOT, VALS, UU>), dim3((unsigned)blocks), dim3(BLOCK), lds, s, A.row_ptr, \
+			   (const u32 *)A.col_idx, A.val, A.palette, X, Y, Vd, (long long)A.rows, c.n, A.st_rpg, A.st_capw, accum, \
+			   A.heavy_thr, c.m, partial, xt, ctl)
+	if constexpr (G >= 8 && !DOT) {
+		if (deep)
+			STAGED_GO(8);
+		else
+			STAGED_GO(4);
+	} else {
+		STAGED_GO(4);
+	}
+#undef STAGED_GO
+}
+
+template <typename W, int MERS, bool DOT>
+static hipError_t staged_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum,
+				  u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
+{
+	int G = 1;
+	while (G < c.n)
+		G <<= 1;
+	const long long TR = (long long)(64 / G) * A.st_rpg, nt = (A.rows + TR - 1) / TR;
+	long long blocks = (nt + BLOCK / 64 - 1) / (BLOCK / 64);
+	long long cap = (long long)c.num_cu * A.st_per_cu;
+	long long hb = heavy_blocks(c, A, 1 << 30), cb = 0, mb = 0;
+	if (DOT) {	/* one partial row per block of every launch that feeds the inner products */
+		hb = heavy_blocks(c, A, max_blocks / 4);
+		cb = A.n_multi ? combine_blocks(A, c.n) : 0;
+		mb = A.n_medium ? medium_blocks(c, A) : 0;
+		const long long room = ((long long)max_blocks - hb - cb - mb) & ~7ll;
+		cap = cap < room ? cap : room;
+	}
+	blocks = blocks > cap ? cap : blocks;
+	blocks = (blocks + 7) & ~7ll;		/* whole rounds of the eight XCDs */
+	if (blocks == ((cap + 7) & ~7ll) && blocks >= 64) {
+		/* A wavefront walks its XCD's tiles with a fixed stride, so the launch takes ceil(T / waves) rounds of tiles
+		 * and the last round is partly empty (GL7d19 shape: 9954 tiles per XCD over 512 wavefronts = 19.4 rounds: the
+		 * twentieth runs with 43 % of the chip, measured +3 % on the launch).  Give up to 15 % of the wavefronts away
+		 * so that the rounds come out (nearly) full: the fabric, not the number of resident waves, bounds the kernel. */
+		long long T = 0;
+		for (int x = 0; x < 8; x++)
+			T = std::max(T, A.st_tiles[x + 1] - A.st_tiles[x]);
+		const long long W4 = BLOCK / 64, bmax = blocks / 8, bmin = std::max<long long>(1, bmax * 85 / 100);
+		long long best = bmax;
+		double best_fill = 0.0;
+		for (long long b = bmax; b >= bmin; b--) {
+			const long long rounds = (T + b * W4 - 1) / (b * W4);
+			const double fill = (double)T / (double)(rounds * b * W4);
+			if (fill > best_fill + 1e-9) {
+				best_fill = fill;
+				best = b;
+			}
+		}
+		blocks = best * 8;
+	}
+	if (DOT)
+		*nblocks = (int)(blocks + hb + cb + mb);
+	const int vals = A.palette ? V_PACKED : (A.val ? V_ARRAY : V_ONES);
+#define STAGED_G(GG)                                                                                              \
+	case GG:                                                                                                  \
+		if (vals == V_PACKED)                                                                             \
+			staged_launch<W, MERS, DOT, GG, V_PACKED>(c, A, X, Y, Vd, accum, partial, blocks, ctl, s); \
+		else if (vals == V_ARRAY)                                                                         \
+			staged_launch<W, MERS, DOT, GG, V_ARRAY>(c, A, X, Y, Vd, accum, partial, blocks, ctl, s);  \
+		else                                                                                              \
+			staged_launch<W, MERS, DOT, GG, V_ONES>(c, A, X, Y, Vd, accum, partial, blocks, ctl, s);   \
+		if (A.n_heavy || A.n_medium)                                                                      \
+			launch_heavy<W, GG, MERS, DOT>(c, A, X, Y, Vd, accum, partial, (int)blocks, hb, ctl, s);      \
+		break;
+	if constexpr (DOT) {
+		switch (G) {
+			STAGED_G(1)
+			STAGED_G(2)
+			STAGED_G(4)
+			STAGED_G(8)
+		default:
+			return hipErrorInvalidValue;
+		}
+	} else {
+		switch (G) {
+			STAGED_G(1)
+			STAGED_G(2)
+			STAGED_G(4)
+			STAGED_G(8)
+			STAGED_G(16)
+			STAGED_G(32)
+			STAGED_G(64)
+		default:
+			return hipErrorInvalidValue;
+		}
+	}
+#undef STAGED_G
+	return hipGetLastError();
 }
 
 template <typename W, int MERS>

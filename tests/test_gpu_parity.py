@@ -343,3 +343,46 @@ def test_abi_misuse_is_reported_not_crashed():
             ctx.set_matrix(M, False, 2, 2)               # rank out of range
         ctx.set_matrix(M, True)                          # re-loading another orientation is fine
         assert ctx.rows(blz.V) == 30 and ctx.rows(blz.TMP) == 40
+
+
+@pytest.mark.parametrize("capw,rpg", [(None, None), ("64", "8"), ("128", "1"), ("4096", "3")])
+@pytest.mark.parametrize("n,p,kind", [(8, P61, "packed"), (4, 2147483647, "packed"), (16, P61, "ones"), (1, 65537, "array"),
+                                      (2, P61, "array"), (8, (1 << 62) - 57, "array"), (32, 1073741789, "packed"),
+                                      (64, P61, "ones")])
+def test_staged_matrix_stream_against_oracle(monkeypatch, n, p, kind, capw, rpg):
+    """k_spmv_staged: the tile's piece of col_idx (and val) is copied into LDS by LDS-DMA one tile ahead, tiles are
+    dealt to the XCDs in nnz-balanced ranges, row tails are predicated batches.  Every value mode (all ones, palette,
+    separate array), window sizes that make rows overflow the staged window (they fall back to reading the stream from
+    global memory) and tile heights from 1 row per lane group up, both orientations, plain and fused-with-block_dot
+    forms, against the oracle; and BLZ_NO_STAGE=1 (the round-1 kernels) gives the same words."""
+    monkeypatch.setenv("BLZ_STAGE_ALWAYS", "1")         # rows of ~19 entries would otherwise keep the round-1 kernels
+    if capw:
+        monkeypatch.setenv("BLZ_STAGE_CAPW", capw)
+        monkeypatch.setenv("BLZ_STAGE_RPG", rpg)
+    rng = np.random.default_rng(n * 1000 + len(kind))
+    nr, nc, nz = 9000, 9500, 170000
+    ii, jj = rng.integers(0, nr, nz), rng.integers(0, nc, nz)
+    ii[:3000] = 17                                        # one outlier row, and rows of very different lengths
+    ii[3000:5000] = rng.integers(100, 140, 2000)
+    if kind == "ones":
+        xx = np.ones(nz, dtype=np.uint32)
+    elif kind == "packed":
+        xx = rng.choice(np.array([1, 2, 3, 2 ** 32 - 1, 2 ** 32 - 2], dtype=np.uint64), size=nz).astype(np.uint32)
+    else:
+        xx = rng.integers(1, 2 ** 32, size=nz, dtype=np.uint64).astype(np.uint32)
+    xx = (xx.astype(np.uint64) % p).astype(np.uint32)
+    M = blz.Matrix(nr, nc, ii, jj, xx)
+    Mo = as_orc(M)
+    for right in (False, True):
+        want = orc.block_lanczos(Mo, n, p, right=right, stop_after=3)
+        for flag in ("0", "1"):
+            monkeypatch.setenv("BLZ_NO_STAGE", flag)
+            with blz.Context(p, n) as ctx:
+                ctx.set_matrix(M, right)
+                x = (np.arange(ctx.rows(blz.TMP) * n, dtype=np.uint64) * 2654435761) % p
+                ctx.set_block(blz.TMP, x)
+                ctx.spmv(right, blz.TMP, blz.AV)
+                assert np.array_equal(ctx.get_block(blz.AV), orc.spmv(Mo, x, right, n, p))
+                ctx.init_v()
+                ctx.iterate(3)
+                assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
