@@ -43,6 +43,12 @@ WORKLOADS = {
     # config 5 at FULL size on one GPU (fits: ~42 GB of the 288 GB HBM); minutes of host-side set-up
     "synth5": dict(desc="config-5 synthetic (all-ones pattern), full size on ONE GPU", rows=50000000, cols=50000000,
                    nnz=2000000000, prime=P61, n=16, right=False, seed=0x53594E35, pattern=True),
+    # EXTRA workload, not a BASELINE config and never the headline: a matrix WITH structure (heavy-tailed column degrees,
+    # banded supports -- the shape of a sieve relation matrix), for what the uniform stand-ins cannot show: the LDS panel
+    # of dense block rows and the per-XCD row ranges of the SpMV
+    "nfs": dict(desc="EXTRA (not a BASELINE config): structured synthetic, 40 % of a row's entries ~1/(c+16), 30 % in a band "
+                     "of 4096 columns, 30 % uniform", rows=2000000, cols=2000000, nnz=40000000, prime=P61, n=8, right=False,
+                seed=0x4E465331, pattern=False, structured=dict(hot_pct=40, band_pct=30, band=4096)),
     "tiny": dict(desc="tiny synthetic (self-test)", rows=20000, cols=15000, nnz=200000, prime=P61,
                  n=8, right=False, seed=0x54494E59, pattern=False),
 }
@@ -107,7 +113,10 @@ def main():
     w = WORKLOADS[args.workload]
     p, n, right = w["prime"], w["n"], w["right"]
     t0 = time.time()
-    M = blz.Matrix.synth(w["rows"], w["cols"], w["nnz"], w["seed"], p, pattern=w["pattern"])
+    if w.get("structured"):
+        M = blz.Matrix.synth_structured(w["rows"], w["cols"], w["nnz"], w["seed"], p, pattern=w["pattern"], **w["structured"])
+    else:
+        M = blz.Matrix.synth(w["rows"], w["cols"], w["nnz"], w["seed"], p, pattern=w["pattern"])
     t_gen = time.time() - t0
 
     ctx = blz.Context(p, n, device=local_rank)
@@ -211,7 +220,8 @@ def main():
                         f"{'--right' if right else '--left'}",
             "step": "one block-Lanczos iteration: 2 block SpMV + block_dot + semi_inverse + orthogonalize",
             "parallelism": "single GPU" if world == 1 else f"row-partition x{world} + RCCL all-gather/all-reduce",
-            "matrix": "seeded synthetic, uniform columns (SURVEY 8(d)); real .mtx not on the box",
+            "matrix": ("seeded synthetic WITH structure (extra workload)" if w.get("structured") else
+                       "seeded synthetic, uniform columns (SURVEY 8(d)); real .mtx not on the box"),
         },
         "roofline": {
             "kernel": "k_spmv (first SpMV of each step: tmp = M^T v)",
@@ -236,6 +246,10 @@ def main():
         "device_ms_per_step": dev_ms / args.steps,
         "kernels": kernels,
         "setup_s": {"generate": t_gen, "csr_upload_init": t_setup},
+        # block rows of each product's operand kept in LDS and the share of the entries they serve (0 on uniform matrices)
+        "renumbering": dict(zip(("lines_per_entry", "order"), (lambda l, k: (dict(zip(("M", "Mt"), l)), ("smallest", "file", "mean")[k]))(*ctx.locality()))),
+        "lds_panel": {"spmv1": dict(zip(("rows", "share"), ctx.panel_rows(not right))),
+                      "spmv2": dict(zip(("rows", "share"), ctx.panel_rows(right)))},
     }
 
     # ---- CPU baseline on this box's host cores: bounded sample of the same workload ------------

@@ -130,6 +130,9 @@ struct blz_ctx {
 	hipGraphExec_t iter_graph = nullptr;
 	bool external_exchange = false;
 	bool force_comm = false;	/* BLZ_FORCE_COMM=1: issue the collectives even on one rank (plumbing test) */
+	double hot_share[2] = { 0.0, 0.0 };	/* share of the entries held by the rows / columns numbered first */
+	double locality[2] = { 1.0, 1.0 };	/* lines per gathered entry in windows of rows, product M*x / M^T*x */
+	int order_kind = 0;			/* which order blz_reorder_auto chose */
 };
 
 /* HIP-event span around one enqueue on the context's stream (only while profiling is on). */
@@ -238,6 +241,10 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 		const char *ns = getenv("BLZ_NO_STAGE");
 		c->cfg.staged = !(ns && ns[0] == '1');
 	}
+	{
+		const char *npn = getenv("BLZ_NO_PANEL");
+		c->cfg.panel = !(npn && npn[0] == '1');
+	}
 	const char *np = getenv("BLZ_NO_PACK");
 	c->pack = !(np && np[0] == '1');
 	const char *nr = getenv("BLZ_NO_REORDER");
@@ -307,7 +314,7 @@ extern "C" void blz_destroy(blz_ctx *c)
 
 extern "C" int blz_word_bytes(const blz_ctx *c) { return c ? c->cfg.word : 0; }
 
-static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
+static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D, int64_t hot_rows = 0)
 {
 	free_csr(D);
 	D.rows = H.rows;
@@ -408,6 +415,7 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D)
 		HIPCHK(hipMalloc(&D.heavy_scratch, heavy.size() * 64 * 2 * sizeof(u64)));
 	}
 	spmv_plan_staged(c->cfg, H.row_ptr, D);
+	spmv_plan_panel(c->cfg, H.row_ptr, D, hot_rows);
 	return BLZ_OK;
 }
 
@@ -457,6 +465,10 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 	c->bounds[0].assign((size_t)nranks + 1, 0);
 	c->bounds[1].assign((size_t)nranks + 1, 0);
 	int rc;
+	int64_t hot[2] = { 0, 0 };	/* densest rows / columns of M numbered first (single rank only) */
+	c->hot_share[0] = c->hot_share[1] = 0.0;
+	c->locality[0] = c->locality[1] = 1.0;
+	c->order_kind = 0;
 	for (int sd = 0; sd < 2; sd++) {
 		c->perm[sd].clear();
 		c->inv[sd].clear();
@@ -466,7 +478,27 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 		const int rs = right ? 1 : 0, cs = 1 - rs;	/* side of M's rows / columns */
 		c->perm[rs].resize((size_t)M->nrows);
 		c->perm[cs].resize((size_t)M->ncols);
-		if ((rc = blz_reorder(M, c->perm[rs].data(), c->perm[cs].data())) != BLZ_OK)
+		/* The renumbering: densest rows / columns in front when they hold enough of the entries (one rank, products in
+		 * one piece: the SpMV keeps that many block rows of its operand in LDS, k_spmv_panel), and behind them the
+		 * order that makes windows of consecutive rows touch the fewest lines of the operand (blz_reorder_auto). */
+		if (c->cfg.panel && nranks == 1 && K == 1) {
+			int64_t cap = spmv_panel_capacity(c->cfg);
+			if (const char *e = getenv("BLZ_PANEL_ROWS"))
+				cap = std::min<int64_t>(cap, std::max<int64_t>(0, atoll(e)));
+			hot[0] = hot[1] = cap;
+		}
+		double min_share = 0.25;	/* below that the dense block rows are served from L2 at no cost to the fabric: measured
+						 * on the structured workload, 17 % of the entries in the panel = no change in time */
+		if (const char *e = getenv("BLZ_PANEL_MIN_PCT"))
+			min_share = atof(e) / 100.0;
+		const int rows_per_line = std::max(1, 128 / (c->cfg.n * c->cfg.word));
+		const char *ao = getenv("BLZ_REORDER_PLAIN");	/* 1: round 1's order without the scored choice (A/B) */
+		if (ao && ao[0] == '1')
+			rc = blz_reorder_hot(M, c->perm[rs].data(), c->perm[cs].data(), hot, min_share, c->hot_share);
+		else
+			rc = blz_reorder_auto(M, c->perm[rs].data(), c->perm[cs].data(), hot, min_share, c->hot_share, rows_per_line,
+					      c->locality, &c->order_kind);
+		if (rc != BLZ_OK)
 			return rc;
 		for (int sd = 0; sd < 2; sd++) {
 			c->inv[sd].resize(c->perm[sd].size());
@@ -495,7 +527,17 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 	}
 	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
 		if (K == 1) {
-			rc = upload_csr(c, slabs[t], c->csr[t][0]);
+			/* product t gathers block rows by the column index of slabs[t]: columns of M for t = 0, rows of M for t = 1 */
+			const int64_t hot_t = hot[t == 0 ? 1 : 0];
+			if (hot_t > 0)
+				blz_csr_sort_rows(&slabs[t]);
+			rc = upload_csr(c, slabs[t], c->csr[t][0], hot_t);
+			{
+				const char *xe = getenv("BLZ_XCD_RANGES");	/* 0 / 1 force it off / on (A/B) */
+				/* (an operand of a few MB sits in every L2 anyway: nothing to separate) */
+				const bool big = (double)slabs[t].cols * c->cfg.n * c->cfg.word > 8e6;
+				c->csr[t][0].xcd_ranges = xe ? xe[0] == '1' : (c->locality[t] < 0.6 && big);
+			}
 		} else {
 			/* columns are positions in the gathered operand of the opposite side: piece k = [k*w, (k+1)*w) */
 			const int cs = 1 - c->row_side[t];
@@ -567,6 +609,27 @@ extern "C" int64_t blz_local_nnz(const blz_ctx *c, int transpose)
 	for (const auto &A : c->csr[transpose ? 1 : 0])
 		nnz += A.nnz;
 	return nnz;
+}
+
+extern "C" int blz_locality(const blz_ctx *c, double locality[2], int *order_kind)
+{
+	if (!c || !c->have_matrix || !locality)
+		return blz_fail(BLZ_EINVAL, "blz_locality: bad argument");
+	locality[0] = c->locality[0];
+	locality[1] = c->locality[1];
+	if (order_kind)
+		*order_kind = c->order_kind;
+	return BLZ_OK;
+}
+
+extern "C" int64_t blz_panel_rows(const blz_ctx *c, int transpose, double *share)
+{
+	if (!c || !c->have_matrix)
+		return -1;
+	const int t = transpose ? 1 : 0;
+	if (share)
+		*share = c->hot_share[t == 0 ? 1 : 0];
+	return c->csr[t].empty() ? 0 : c->csr[t][0].panel_rows;
 }
 
 extern "C" int64_t blz_matrix_stream_bytes(const blz_ctx *c, int transpose)

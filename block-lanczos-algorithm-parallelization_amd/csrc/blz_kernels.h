@@ -16,6 +16,11 @@ struct HeavyRow {
 	int row, first, count;	/* a split row: segments [first, first + count) of the list */
 };
 
+/* rows [begin[x], begin[x+1]) belong to XCD x (blocks b and b + 8 share an XCD); begin[0] < 0: no ranges */
+struct XcdRows {
+	long long begin[9];
+};
+
 /* One CSR slab resident in HBM. */
 struct DevCsr {
 	int64_t rows = 0, cols = 0, nnz = 0;
@@ -39,6 +44,10 @@ struct DevCsr {
 	int st_capw = 0;		/* staging window per wavefront and buffer, entries */
 	int st_per_cu = 0;		/* resident workgroups per CU the grid is sized for */
 	int st_ns = 1;			/* streams staged: col_idx (+ val when it is a separate array) */
+	/* LDS-resident panel of the operand's first panel_rows block rows (k_spmv_panel), set by spmv_plan_panel() */
+	int panel_rows = 0;
+	bool xcd_ranges = false;	/* k_spmv / k_spmv_dot walk per-XCD row ranges (set when the renumbering found locality) */
+	long long xr_rows[9] = { 0 };	/* XCD x takes rows [xr_rows[x], xr_rows[x+1]); xr_rows[0] < 0: equal stripes */
 	int st_interleave = 0;		/* 1: tiles round-robin over the whole grid instead of per-XCD ranges */
 	long long st_tiles[9] = { 0 };	/* XCD x takes tiles [st_tiles[x], st_tiles[x+1]): contiguous, nnz-balanced */
 };
@@ -61,12 +70,18 @@ struct KernelCfg {
 	ModP m;
 	int num_cu;
 	int spmv_blocks_per_cu;	/* grid of the persistent SpMV = num_cu * this (BLZ_SPMV_BLOCKS_PER_CU overrides) */
+	int panel;		/* 1: slabs whose operand has hot block rows run k_spmv_panel; BLZ_NO_PANEL=1 turns it off */
 	int staged;		/* 1: slabs with a plan run k_spmv_staged; BLZ_NO_STAGE=1 keeps the round-1 kernels (A/B) */
 };
 
 /* fills the st_* fields of D from the host copy of its row pointers (D.rows, D.nnz, D.val, D.palette, D.kept_mean,
  * D.uneven must be set) */
 void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D);
+
+/* how many block rows the LDS panel of k_spmv_panel can hold for this context (0: the form is not available) */
+int64_t spmv_panel_capacity(const KernelCfg &c);
+/* the slab's operand has its `hot_rows` densest block rows numbered first: plan k_spmv_panel (D.rows, D.nnz, D.cols set) */
+void spmv_plan_panel(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, int64_t hot_rows);
 
 /* rows of a slab with more entries than this get a workgroup each (DevCsr::heavy) */
 u32 spmv_heavy_threshold(const KernelCfg &c, int64_t rows, int64_t nnz);

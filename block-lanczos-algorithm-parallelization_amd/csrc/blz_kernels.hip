@@ -243,7 +243,7 @@ template <typename W, int G, int MERS>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
        const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, long long rows, int n, int split_log2,
-       int accum, u32 heavy, ModP m, const DevCtl *__restrict__ ctl)
+       int accum, u32 heavy, ModP m, XcdRows xr, const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
@@ -259,8 +259,17 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 	const long long gid = ((long long)blockIdx.x * BLOCK + threadIdx.x) / G;
 	const long long g0 = gid >> split_log2;
 	const u32 part = (u32)gid & ((1u << split_log2) - 1u);
-	const long long ng = ((long long)gridDim.x * (BLOCK / G)) >> split_log2;
-	for (long long r = g0; r < rows; r += ng) {
+	long long ng = ((long long)gridDim.x * (BLOCK / G)) >> split_log2;
+	long long r = g0;
+	if (xr.begin[0] >= 0) {
+		/* per-XCD row ranges (matrices whose neighbouring rows share columns; split_log2 == 0, grid a multiple of 8):
+		 * blocks b and b + 8 share an XCD, so each L2 serves one contiguous eighth of the rows */
+		const int xcd = blockIdx.x & 7;
+		r = xr.begin[xcd] + ((long long)(blockIdx.x >> 3) * BLOCK + threadIdx.x) / G;
+		rows = xr.begin[xcd + 1];
+		ng = (long long)(gridDim.x >> 3) * (BLOCK / G);
+	}
+	for (; r < rows; r += ng) {
 		u32 k = rp[r], e = rp[r + 1];
 		if (e - k > heavy)	/* left to k_spmv_heavy */
 			continue;
@@ -311,12 +320,19 @@ template <typename W, int MERS, bool DOT>
 static hipError_t staged_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum,
 				  u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s);
 
+/* ... and with the densest block rows of the operand resident in LDS (k_spmv_panel, below) */
+template <typename W, int MERS, bool DOT>
+static hipError_t panel_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum,
+				 u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s);
+
 template <typename W, int MERS>
 static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, int accum, const DevCtl *ctl,
 				hipStream_t s)
 {
 	if (A.rows == 0)
 		return hipSuccess;
+	if (A.panel_rows > 0 && c.panel)
+		return panel_dispatch<W, MERS, false>(c, A, X, Y, (const W *)nullptr, accum, (u64 *)nullptr, 0, (int *)nullptr, ctl, s);
 	if (A.st_ok && c.staged)
 		return staged_dispatch<W, MERS, false>(c, A, X, Y, (const W *)nullptr, accum, (u64 *)nullptr, 0, (int *)nullptr, ctl, s);
 	int G = 1;
@@ -340,11 +356,18 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 	const long long cap = (long long)c.num_cu * per_cu;
 	if (blocks > cap)
 		blocks = cap;
+	XcdRows xr;
+	xr.begin[0] = -1;
+	if (A.xcd_ranges && split_log2 == 0 && blocks >= 64) {
+		for (int x = 0; x < 9; x++)
+			xr.begin[x] = A.xr_rows[x];
+		blocks = (blocks + 7) & ~7ll;
+	}
 #define SPMV_CASE(GG)                                                                                             \
 	case GG:                                                                                                  \
 		hipLaunchKernelGGL((k_spmv<W, GG, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr,  \
 				   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, accum,     \
-				   A.heavy_thr, c.m, ctl);                                                         \
+				   A.heavy_thr, c.m, xr, ctl);                                                     \
 		if (A.n_heavy || A.n_medium)                                                                      \
 			launch_heavy<W, GG, MERS, false>(c, A, X, Y, (const W *)nullptr, accum, (u64 *)nullptr, 0,   \
 							 heavy_blocks(c, A, 1 << 30), ctl, s);                        \
@@ -463,9 +486,9 @@ k_block_dot(const W *__restrict__ V, const W *__restrict__ AV, long long rows, l
  * in 128-bit registers, reduced every m.chunk rows.  Used stand-alone (k_block_dot_fast) and as the epilogue
  * of the second SpMV (k_spmv_dot), where its VALU work hides under the gather latency.
  */
-template <typename A, int MERS, int NT>
+template <typename A, int MERS, int NT, int BS = BLOCK>
 struct DotState {
-	static constexpr int H = NT / 2 + 1, SLOTS = NT + H, WAVES = BLOCK / 64;
+	static constexpr int H = NT / 2 + 1, SLOTS = NT + H, WAVES = BS / 64;
 	A a1[NT], a2[H];
 	u32 cnt;
 
@@ -530,7 +553,7 @@ struct DotState {
 				red[t >> 6][q][i] = x;
 		}
 		__syncthreads();
-		for (int e = t; e < SLOTS * NT; e += BLOCK) {
+		for (int e = t; e < SLOTS * NT; e += BS) {
 			const int q = e / NT, ii = e % NT;
 			u64 x = 0;
 #pragma unroll
@@ -651,7 +674,8 @@ template <typename W, int MERS, int NT>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
 	   const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
-	   long long rows, int accum, u32 heavy, ModP m, u64 *__restrict__ partial, const DevCtl *__restrict__ ctl)
+	   long long rows, int accum, u32 heavy, ModP m, u64 *__restrict__ partial, XcdRows xr,
+	   const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
@@ -663,11 +687,17 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 		spal_store[threadIdx.x] = pal[threadIdx.x];
 	__syncthreads();
 	const int t = threadIdx.x, lane = t & (NT - 1), gbase = (t & 63) - lane;
-	const long long g0 = ((long long)blockIdx.x * BLOCK + t) / NT;
-	const long long ng = (long long)gridDim.x * (BLOCK / NT);
+	long long r = ((long long)blockIdx.x * BLOCK + t) / NT;
+	long long ng = (long long)gridDim.x * (BLOCK / NT);
+	if (xr.begin[0] >= 0) {		/* per-XCD row ranges, as in k_spmv */
+		const int xcd = blockIdx.x & 7;
+		r = xr.begin[xcd] + ((long long)(blockIdx.x >> 3) * BLOCK + t) / NT;
+		rows = xr.begin[xcd + 1];
+		ng = (long long)(gridDim.x >> 3) * (BLOCK / NT);
+	}
 	DS ds;
 	ds.init();
-	for (long long r = g0; r < rows; r += ng) {
+	for (; r < rows; r += ng) {
 		const u32 k = rp[r], e = rp[r + 1];
 		if (e - k > heavy)	/* row and its share of the inner products: k_spmv_heavy */
 			continue;
@@ -823,6 +853,8 @@ template <typename W, int MERS>
 static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum,
 				    u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
 {
+	if (A.panel_rows > 0 && c.panel)
+		return panel_dispatch<W, MERS, true>(c, A, X, Y, Vd, accum, partial, max_blocks, nblocks, ctl, s);
 	if (A.st_ok && c.staged)
 		return staged_dispatch<W, MERS, true>(c, A, X, Y, Vd, accum, partial, max_blocks, nblocks, ctl, s);
 	const long long gpb = BLOCK / c.n;
@@ -835,11 +867,18 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 	const long long room = max_blocks - hb - cb - mb;
 	const long long cap = (long long)c.num_cu * per_cu < room ? (long long)c.num_cu * per_cu : room;
 	blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+	XcdRows xr;
+	xr.begin[0] = -1;
+	if (A.xcd_ranges && blocks >= 64 && (blocks & ~7ll) >= 64) {
+		for (int x = 0; x < 9; x++)
+			xr.begin[x] = A.xr_rows[x];
+		blocks &= ~7ll;		/* whole rounds of the XCDs, still within the room for partial rows */
+	}
 	*nblocks = (int)(blocks + hb + cb + mb);
 #define SPMV_DOT(NN)                                                                                                \
 	case NN:                                                                                                    \
 		hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
-				   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, A.heavy_thr, c.m, partial, ctl); \
+				   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, A.heavy_thr, c.m, partial, xr, ctl); \
 		if (hb || mb)                                                                                       \
 			launch_heavy<W, NN, MERS, true>(c, A, X, Y, Vd, accum, partial, (int)blocks, hb, ctl, s);      \
 		break;
@@ -1236,6 +1275,222 @@ static hipError_t staged_dispatch(const KernelCfg &c, const DevCsr &A, const W *
 		}
 	}
 #undef STAGED_G
+	return hipGetLastError();
+}
+
+/* ------------------------------------------ SpMV with a panel of dense block rows resident in LDS (round 2) */
+
+/*
+ * Matrices with heavy-tailed column degrees (sieve relation matrices: the columns of the small primes hold a large
+ * share of the entries) gather the same few block rows of X over and over.  The host numbers the densest rows and
+ * columns first (blz_reorder_hot) and sorts every row's entries by column, so the first `H` block rows of the operand
+ * are the hot ones and a row's hot entries come first.  One workgroup of 1024 threads per CU copies X[0..H) into LDS
+ * (up to 128 KB) and keeps it for the whole launch: an entry with column < H reads its block row from LDS, the others
+ * are gathered as in k_spmv.  The gather ceiling (~55 G line fills per second, whatever the row size) then applies to
+ * the cold entries only (tools/ubench2 q3: half of the entries in the panel = 1.9 x the rows per second).
+ * Rows are dealt to XCDs in contiguous nnz-balanced ranges (blocks b and b + 8 share an XCD), so neighbouring rows with
+ * overlapping column supports meet in one 4 MB L2 instead of being fetched into all eight.
+ * DOT: block_dot_products as the epilogue, as in k_spmv_dot (n = G in {1,2,4,8}).
+ */
+#define PBLOCK 1024
+#define PANEL_BYTES (128 * 1024)
+
+template <typename W, int G, int MERS, bool DOT, int VALS>
+__global__ void __launch_bounds__(PBLOCK)
+k_spmv_panel(const u32 *__restrict__ rp, const u32 *__restrict__ ci, const u32 *__restrict__ va,
+	     const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd, int accum,
+	     u32 heavy, ModP m, u64 *__restrict__ partial, XcdRows xr, u32 H, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int NT = DOT ? G : 1;
+	using DS = DotState<typename std::conditional<sizeof(W) == 4, AccS, Acc>::type, MERS, NT, PBLOCK>;
+	__shared__ u64 red[DS::WAVES][DS::SLOTS][NT];
+	__shared__ u32 spal[256];
+	extern __shared__ __attribute__((aligned(16))) unsigned char panel_raw[];
+	W *panel = (W *)panel_raw;
+	const int t = threadIdx.x, lane = t & (G - 1), gbase = (t & 63) - lane;
+	if (VALS == V_PACKED && t < 256)
+		spal[t] = pal[t];
+	for (u32 i = (u32)t; i < H * (u32)G; i += PBLOCK)
+		panel[i] = X[i];
+	__syncthreads();
+	const int xcd = blockIdx.x & 7;
+	const long long ng = (long long)(gridDim.x >> 3) * (PBLOCK / G);
+	const long long g0 = xr.begin[xcd] + (long long)(blockIdx.x >> 3) * (PBLOCK / G) + t / G;
+	const long long rend = xr.begin[xcd + 1];
+	const u32 Hm1 = H - 1;
+	DS ds;
+	if (DOT)
+		ds.init();
+	for (long long r = g0; r < rend; r += ng) {
+		u32 k = rp[r];
+		const u32 e = rp[r + 1];
+		if (e - k > heavy)
+			continue;
+		u64 vi = 0;
+		if (DOT)
+			vi = Vd[(size_t)r * G + lane];
+		Acc acc;
+		acc_zero(acc);
+		for (; k < e; k += 4) {
+			u32 c[4], a[4];
+			W x[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const u32 at = k + j < e ? k + j : e - 1;
+				const u32 pk = ci[at];
+				c[j] = VALS == V_PACKED ? (pk & 0xFFFFFFu) : pk;
+				if (VALS == V_PACKED)
+					a[j] = spal[pk >> 24];
+				else if (VALS == V_ARRAY)
+					a[j] = va[at];
+				else
+					a[j] = 1u;
+				if (k + j >= e)
+					a[j] = 0u;
+			}
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const W hot = panel[(size_t)(c[j] < H ? c[j] : Hm1) * G + lane];
+				W cold = 0;
+				if (c[j] >= H)
+					cold = X[(size_t)c[j] * G + lane];
+				x[j] = c[j] < H ? hot : cold;
+			}
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				if (VALS == V_ONES)
+					acc_add(acc, a[j] ? (u64)x[j] : 0ull);
+				else
+					acc_mac32(acc, a[j], x[j]);
+			}
+		}
+		if (accum)
+			acc_add(acc, Y[(size_t)r * G + lane]);
+		const u64 y = acc_reduce<MERS>(acc, m);
+		Y[(size_t)r * G + lane] = (W)y;
+		if (DOT)
+			ds.row(vi, y, lane, gbase, m);
+	}
+	if (DOT)
+		ds.finish(red, partial, m, (int)blockIdx.x);
+}
+
+/* rows of the panel an operand of width G words of `word` bytes can have */
+int64_t spmv_panel_capacity(const KernelCfg &c)
+{
+	int G = 1;
+	while (G < c.n)
+		G <<= 1;
+	if (G != c.n)		/* exact-width blocks (BLZ_NO_PAD): no panel */
+		return 0;
+	return PANEL_BYTES / ((int64_t)G * c.word);
+}
+
+void spmv_plan_panel(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, int64_t hot_rows)
+{
+	D.panel_rows = 0;
+	if (D.rows <= 0 || D.nnz <= 0)
+		return;
+	if (hot_rows > 0 && hot_rows <= spmv_panel_capacity(c) && hot_rows <= D.cols)
+		D.panel_rows = (int)hot_rows;
+	/* nnz-balanced row ranges of the eight XCDs (used by k_spmv_panel always, by k_spmv / k_spmv_dot when the slab's
+	 * rows have local column supports: DevCsr::xcd_ranges) */
+	D.xr_rows[0] = 0;
+	{
+		/* balanced by the entries the streaming kernel keeps: rows above the outlier threshold go to other launches, and
+		 * on a heavy-tailed matrix (renumbered: densest rows first) they would otherwise fill the first XCD's share */
+		double kept = 0.0;
+		for (int64_t r = 0; r < D.rows; r++) {
+			const u32 len = row_ptr[r + 1] - row_ptr[r];
+			kept += len <= D.heavy_thr ? (double)len : 0.0;
+		}
+		double run = 0.0;
+		int x = 1;
+		for (int64_t r = 0; r < D.rows && x < 8; r++) {
+			const u32 len = row_ptr[r + 1] - row_ptr[r];
+			run += len <= D.heavy_thr ? (double)len : 0.0;
+			while (x < 8 && run >= kept * x / 8.0)
+				D.xr_rows[x++] = r + 1;
+		}
+		for (; x < 8; x++)
+			D.xr_rows[x] = D.rows;
+	}
+	D.xr_rows[8] = D.rows;
+	if (const char *e = getenv("BLZ_PANEL_STRIPES"))	/* experiments: 1 = eight equal stripes by row count */
+		if (e[0] == '1')
+			D.xr_rows[0] = -1;
+}
+
+template <typename W, int MERS, bool DOT, int G, int VALS>
+static void panel_launch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum, u64 *partial,
+			 long long blocks, const DevCtl *ctl, hipStream_t s)
+{
+	XcdRows xr;
+	for (int x = 0; x < 9; x++)
+		xr.begin[x] = A.xr_rows[0] < 0 ? A.rows * x / 8 : A.xr_rows[x];
+	const size_t lds = (size_t)A.panel_rows * G * sizeof(W);
+	auto kern = k_spmv_panel<W, G, MERS, DOT, VALS>;
+	static bool attr_set = false;	/* one flag per instantiation */
+	if (!attr_set) {
+		(void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PBLOCK), lds, s, A.row_ptr, (const u32 *)A.col_idx, A.val,
+			   A.palette, X, Y, Vd, accum, A.heavy_thr, c.m, partial, xr, (u32)A.panel_rows, ctl);
+}
+
+template <typename W, int MERS, bool DOT>
+static hipError_t panel_dispatch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, const W *Vd, int accum,
+				 u64 *partial, int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
+{
+	const int G = c.n;	/* spmv_panel_capacity: a power of two */
+	long long blocks = ((long long)c.num_cu + 7) & ~7ll;	/* one workgroup of 1024 per CU, whole rounds of the XCDs */
+	long long hb = heavy_blocks(c, A, 1 << 30), cb = 0, mb = 0;
+	if (DOT) {
+		hb = heavy_blocks(c, A, max_blocks / 4);
+		cb = A.n_multi ? combine_blocks(A, c.n) : 0;
+		mb = A.n_medium ? medium_blocks(c, A) : 0;
+		if (blocks + hb + cb + mb > max_blocks)
+			return hipErrorInvalidValue;
+		*nblocks = (int)(blocks + hb + cb + mb);
+	}
+	const int vals = A.palette ? V_PACKED : (A.val ? V_ARRAY : V_ONES);
+#define PANEL_G(GG)                                                                                              \
+	case GG:                                                                                                 \
+		if (vals == V_PACKED)                                                                            \
+			panel_launch<W, MERS, DOT, GG, V_PACKED>(c, A, X, Y, Vd, accum, partial, blocks, ctl, s); \
+		else if (vals == V_ARRAY)                                                                        \
+			panel_launch<W, MERS, DOT, GG, V_ARRAY>(c, A, X, Y, Vd, accum, partial, blocks, ctl, s);  \
+		else                                                                                             \
+			panel_launch<W, MERS, DOT, GG, V_ONES>(c, A, X, Y, Vd, accum, partial, blocks, ctl, s);   \
+		if (A.n_heavy || A.n_medium)                                                                     \
+			launch_heavy<W, GG, MERS, DOT>(c, A, X, Y, Vd, accum, partial, (int)blocks, hb, ctl, s);     \
+		break;
+	if constexpr (DOT) {
+		switch (G) {
+			PANEL_G(1)
+			PANEL_G(2)
+			PANEL_G(4)
+			PANEL_G(8)
+		default:
+			return hipErrorInvalidValue;
+		}
+	} else {
+		switch (G) {
+			PANEL_G(1)
+			PANEL_G(2)
+			PANEL_G(4)
+			PANEL_G(8)
+			PANEL_G(16)
+			PANEL_G(32)
+			PANEL_G(64)
+		default:
+			return hipErrorInvalidValue;
+		}
+	}
+#undef PANEL_G
 	return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -365,6 +366,75 @@ int blz_synth_coo(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int 
 	return BLZ_OK;
 }
 
+/*
+ * A matrix WITH structure, for the measurements the uniform stand-ins cannot make (it is never the headline workload):
+ * the shape of a sieve relation matrix.  Row r gets floor(nnz/R) (+1) distinct columns,
+ *   hot_pct  % drawn with probability ~ 1/(c + 16): heavy-tailed column degrees (small primes),
+ *   band_pct % uniform in a band of `band` columns centred on r*C/R: correlated supports of neighbouring rows,
+ *   the rest uniform over all columns;
+ * the first column numbers are the dense ones, as in a file sorted by prime.  Values as blz_synth_coo.
+ */
+int blz_synth_structured(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int pattern, uint64_t prime,
+			 int hot_pct, int band_pct, int64_t band, blz_coo *out)
+{
+	static const int32_t palette[7] = { 1, 1, 1, 2, 3, -1, -2 };
+	if (!out || nrows <= 0 || ncols <= 0 || nnz < 0 || prime < 2 || nrows > INT32_MAX || ncols > INT32_MAX ||
+	    hot_pct < 0 || band_pct < 0 || hot_pct + band_pct > 100 || band < 1)
+		return blz_fail(BLZ_EINVAL, "blz_synth_structured: bad argument");
+	const int64_t base = nnz / nrows, extra = nnz % nrows;
+	if (2 * (base + 1) > ncols || 2 * (base + 1) > band)
+		return blz_fail(BLZ_EINVAL, "blz_synth_structured: rows too long for the column range / band");
+	memset(out, 0, sizeof *out);
+	out->nrows = nrows;
+	out->ncols = ncols;
+	out->nnz = nnz;
+	const size_t cap = (size_t)(nnz ? nnz : 1);
+	out->i = malloc(cap * sizeof *out->i);
+	out->j = malloc(cap * sizeof *out->j);
+	out->x = malloc(cap * sizeof *out->x);
+	if (!out->i || !out->j || !out->x) {
+		blz_coo_free(out);
+		return blz_fail(BLZ_ENOMEM, "blz_synth_structured: out of memory");
+	}
+	const double c0 = 16.0, lnr = log(((double)ncols + c0) / c0);
+	if (band > ncols)
+		band = ncols;
+#pragma omp parallel for schedule(static) if (nnz > 200000)
+	for (int64_t r = 0; r < nrows; r++) {
+		const int64_t cnt = base + (r < extra);
+		int64_t at = r * base + (r < extra ? r : extra);
+		uint64_t s = seed ^ ((uint64_t)r * 0xD1342543DE82EF95ull);
+		int64_t lo = (int64_t)((double)r * (double)ncols / (double)nrows) - band / 2;
+		lo = lo < 0 ? 0 : (lo + band > ncols ? ncols - band : lo);
+		for (int64_t k = 0; k < cnt; k++) {
+			const int kind = (int)(splitmix64(&s) % 100);
+			int32_t col;
+			for (int tries = 0;; tries++) {	/* distinct columns within the row */
+				const uint64_t u = splitmix64(&s);
+				if (kind < hot_pct && tries < 8) {
+					const double x = c0 * (exp((double)(u >> 11) * (1.0 / 9007199254740992.0) * lnr) - 1.0);
+					col = (int32_t)(x >= (double)ncols ? ncols - 1 : (int64_t)x);
+				} else if (kind < hot_pct + band_pct && tries < 16) {
+					col = (int32_t)(lo + (int64_t)(u % (uint64_t)band));
+				} else {
+					col = (int32_t)(u % (uint64_t)ncols);
+				}
+				int dup = 0;
+				for (int64_t q = at - k; q < at && !dup; q++)
+					dup = (out->j[q] == col);
+				if (!dup)
+					break;
+			}
+			const int32_t v = pattern ? 1 : palette[splitmix64(&s) % 7];
+			out->i[at] = (int32_t)r;
+			out->j[at] = col;
+			out->x[at] = (uint32_t)((uint64_t)(uint32_t)v % prime);
+			at++;
+		}
+	}
+	return BLZ_OK;
+}
+
 /* ------------------------------------------------------------------------ CSR building */
 
 void blz_csr_free(blz_csr *A)
@@ -592,6 +662,439 @@ int blz_reorder(const blz_coo *M, int32_t *row_perm, int32_t *col_perm)
 	}
 	free(key);
 	return rc;
+}
+
+/* The `want` indices of largest degree (ties: lowest index), by descending degree; returns how many were chosen and the
+ * number of entries they hold.  Degrees are bucketed up to 65535; above that the order inside the top bucket is by index. */
+static int64_t pick_hot(const int32_t *deg, int64_t count, int64_t want, int32_t *hot_list, int64_t *hot_nnz)
+{
+	*hot_nnz = 0;
+	if (want <= 0 || count <= 0)
+		return 0;
+	if (want > count)
+		want = count;
+	int64_t *hist = calloc(65536, sizeof *hist);
+	if (!hist)
+		return 0;
+	for (int64_t q = 0; q < count; q++)
+		hist[deg[q] > 65535 ? 65535 : deg[q]]++;
+	int64_t need = want;
+	int thr = 65535;
+	for (; thr > 0; thr--) {
+		if (hist[thr] >= need)
+			break;
+		need -= hist[thr];
+	}
+	free(hist);
+	/* everything above thr, and the first `need` indices at thr (thr = 0: entries-less indices are never hot) */
+	int64_t got = 0;
+	for (int64_t q = 0; q < count && got < want; q++) {
+		const int d = deg[q] > 65535 ? 65535 : deg[q];
+		if (d == 0)
+			continue;
+		if (d > thr || (d == thr && need-- > 0))
+			hot_list[got++] = (int32_t)q;
+	}
+	/* descending degree (insertion sort: a panel holds at most a few thousand rows) */
+	for (int64_t a = 1; a < got; a++) {
+		const int32_t x = hot_list[a];
+		int64_t b = a;
+		while (b > 0 && deg[hot_list[b - 1]] < deg[x]) {
+			hot_list[b] = hot_list[b - 1];
+			b--;
+		}
+		hot_list[b] = x;
+	}
+	for (int64_t a = 0; a < got; a++)
+		*hot_nnz += deg[hot_list[a]];
+	return got;
+}
+
+/*
+ * blz_reorder with the densest rows and columns numbered first: hot[0] rows and hot[1] columns (in: the most a panel can
+ * hold; out: how many were taken, 0 when they hold less than min_share of the entries -- a uniform matrix gets the plain
+ * locality order).  The first hot[.] block rows of an operand are what the SpMV keeps in LDS (k_spmv_panel); the other
+ * rows are ordered by their smallest NON-hot column (a dense column would otherwise be everybody's smallest) and the
+ * other columns by their smallest non-hot new row.
+ */
+int blz_reorder_hot(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int64_t hot[2], double min_share, double share[2])
+{
+	if (!M || !row_perm || !col_perm || !hot || !share)
+		return blz_fail(BLZ_EINVAL, "blz_reorder_hot: bad argument");
+	const int64_t N[2] = { M->nrows, M->ncols };
+	const int64_t big = N[0] > N[1] ? N[0] : N[1];
+	int32_t *deg = calloc((size_t)big + 1, sizeof *deg), *key = malloc(sizeof *key * (size_t)(big + 1));
+	int32_t *list[2] = { NULL, NULL };
+	unsigned char *is_hot[2] = { calloc((size_t)N[0] + 1, 1), calloc((size_t)N[1] + 1, 1) };
+	int rc = BLZ_OK;
+	if (!deg || !key || !is_hot[0] || !is_hot[1])
+		rc = blz_fail(BLZ_ENOMEM, "blz_reorder_hot: out of memory");
+	for (int sd = 0; sd < 2 && rc == BLZ_OK; sd++) {
+		const int32_t *idx = sd == 0 ? M->i : M->j;
+		memset(deg, 0, sizeof *deg * (size_t)(N[sd] + 1));
+		for (int64_t k = 0; k < M->nnz; k++)
+			deg[idx[k]]++;
+		list[sd] = malloc(sizeof(int32_t) * (size_t)(hot[sd] > 0 ? hot[sd] : 1));
+		if (!list[sd]) {
+			rc = blz_fail(BLZ_ENOMEM, "blz_reorder_hot: out of memory");
+			break;
+		}
+		int64_t held = 0;
+		int64_t got = pick_hot(deg, N[sd], hot[sd], list[sd], &held);
+		share[sd] = M->nnz > 0 ? (double)held / (double)M->nnz : 0.0;
+		if (share[sd] < min_share)
+			got = 0;
+		hot[sd] = got;
+		for (int64_t a = 0; a < got; a++)
+			is_hot[sd][list[sd][a]] = 1;
+	}
+	if (rc == BLZ_OK) {
+		/* rows: hot ones first (by degree), then by smallest non-hot column */
+		for (int64_t r = 0; r < M->nrows; r++)
+			key[r] = (int32_t)M->ncols;
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
+		for (int64_t k = 0; k < M->nnz; k++)
+			if (!is_hot[1][M->j[k]])
+				atomic_min_i32(&key[M->i[k]], M->j[k]);
+		rc = sort_by_key(key, M->nrows, M->ncols, row_perm);	/* positions 0..R-1 among ALL rows */
+	}
+	if (rc == BLZ_OK && hot[0] > 0) {
+		/* squeeze the hot rows out of that order and put them in front */
+		int32_t *order = malloc(sizeof *order * (size_t)M->nrows);
+		if (!order) {
+			rc = blz_fail(BLZ_ENOMEM, "blz_reorder_hot: out of memory");
+		} else {
+			for (int64_t r = 0; r < M->nrows; r++)
+				order[row_perm[r]] = (int32_t)r;
+			int64_t at = hot[0];
+			for (int64_t q = 0; q < M->nrows; q++)
+				if (!is_hot[0][order[q]])
+					row_perm[order[q]] = (int32_t)at++;
+			for (int64_t a = 0; a < hot[0]; a++)
+				row_perm[list[0][a]] = (int32_t)a;
+			free(order);
+		}
+	}
+	if (rc == BLZ_OK) {
+		for (int64_t c = 0; c < M->ncols; c++)
+			key[c] = (int32_t)M->nrows;
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
+		for (int64_t k = 0; k < M->nnz; k++)
+			if (!is_hot[0][M->i[k]])
+				atomic_min_i32(&key[M->j[k]], row_perm[M->i[k]]);
+		rc = sort_by_key(key, M->ncols, M->nrows, col_perm);
+	}
+	if (rc == BLZ_OK && hot[1] > 0) {
+		int32_t *order = malloc(sizeof *order * (size_t)M->ncols);
+		if (!order) {
+			rc = blz_fail(BLZ_ENOMEM, "blz_reorder_hot: out of memory");
+		} else {
+			for (int64_t c = 0; c < M->ncols; c++)
+				order[col_perm[c]] = (int32_t)c;
+			int64_t at = hot[1];
+			for (int64_t q = 0; q < M->ncols; q++)
+				if (!is_hot[1][order[q]])
+					col_perm[order[q]] = (int32_t)at++;
+			for (int64_t a = 0; a < hot[1]; a++)
+				col_perm[list[1][a]] = (int32_t)a;
+			free(order);
+		}
+	}
+	free(deg);
+	free(key);
+	free(list[0]);
+	free(list[1]);
+	free(is_hot[0]);
+	free(is_hot[1]);
+	return rc;
+}
+
+/* ---- choosing the renumbering by what it does to the gathers (round 2) ----
+ *
+ * Three candidate orders of the non-hot rows / columns:
+ *   SMALLEST   rows by smallest (non-hot) column, columns by smallest new row: blz_reorder's order; on a matrix without
+ *              structure it makes neighbouring rows share the line of their first entry (-8 % line fills, round 1)
+ *   IDENTITY   the file's order: a matrix that arrives banded or block-structured stays so
+ *   BARYCENTRE rows by the mean of their columns, columns by the mean of their new rows: tidies a file that is only
+ *              roughly in band order (one sweep; it does not recover a band from a random shuffle)
+ * Each is scored on a sample of windows of WIN consecutive (new) rows of each product: the number of DISTINCT 128-byte
+ * lines of the operand that the window's entries touch -- what an XCD's L2 has to fetch while its wavefronts walk such
+ * a window.  The order with the fewest lines wins; locality[t] = lines / entries of product t under it (1 = every
+ * entry its own line: nothing to reuse; the per-XCD row ranges of the SpMV are switched on below 0.85).
+ */
+enum { ORD_SMALLEST = 0, ORD_IDENTITY = 1, ORD_BARYCENTRE = 2, ORD_KINDS = 3 };
+
+static int cmp_i32(const void *a, const void *b)
+{
+	const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+	return x < y ? -1 : x > y;
+}
+
+/* entries grouped by idx: start[count + 1], order[nnz] */
+static int group_entries(const int32_t *idx, int64_t count, int64_t nnz, int64_t **start_out, int32_t **order_out)
+{
+	int64_t *start = calloc((size_t)count + 2, sizeof *start);
+	int32_t *order = malloc(sizeof *order * (size_t)(nnz ? nnz : 1));
+	if (!start || !order) {
+		free(start);
+		free(order);
+		return blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
+	}
+	for (int64_t k = 0; k < nnz; k++)
+		start[idx[k] + 1]++;
+	for (int64_t q = 0; q < count; q++)
+		start[q + 1] += start[q];
+	int64_t *fill = malloc(sizeof *fill * (size_t)(count + 1));
+	if (!fill) {
+		free(start);
+		free(order);
+		return blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
+	}
+	memcpy(fill, start, sizeof *fill * (size_t)(count + 1));
+	for (int64_t k = 0; k < nnz; k++)
+		order[fill[idx[k]]++] = (int32_t)k;
+	free(fill);
+	*start_out = start;
+	*order_out = order;
+	return BLZ_OK;
+}
+
+/* lines touched / entries, summed over sampled windows of the product whose rows are `own` and operand rows `other` */
+static void score_product(int64_t n_own, const int32_t *perm_own, const int32_t *other_idx, const int32_t *perm_other,
+			  const int64_t *start, const int32_t *order, int line_shift, int64_t win, int samples,
+			  const unsigned char *skip_other, double *lines_out, double *entries_out)
+{
+	int32_t *inv = malloc(sizeof *inv * (size_t)(n_own ? n_own : 1));
+	double lines = 0.0, entries = 0.0;
+	if (inv) {
+		for (int64_t r = 0; r < n_own; r++)
+			inv[perm_own[r]] = (int32_t)r;
+		if (win > n_own)
+			win = n_own;
+		const int64_t nwin = n_own / win > 0 ? n_own / win : 1;
+		if (samples > nwin)
+			samples = (int)nwin;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : lines, entries)
+		for (int sidx = 0; sidx < samples; sidx++) {
+			const int64_t w0 = (nwin * sidx / samples) * win;
+			int64_t cnt = 0;
+			for (int64_t q = w0; q < w0 + win && q < n_own; q++)
+				cnt += start[inv[q] + 1] - start[inv[q]];
+			int32_t *buf = malloc(sizeof *buf * (size_t)(cnt ? cnt : 1));
+			if (!buf)
+				continue;
+			int64_t at = 0;
+			for (int64_t q = w0; q < w0 + win && q < n_own; q++)
+				for (int64_t k = start[inv[q]]; k < start[inv[q] + 1]; k++) {
+					const int32_t o = other_idx[order[k]];
+					if (skip_other && skip_other[o])	/* panel rows are not gathered */
+						continue;
+					buf[at++] = perm_other[o] >> line_shift;
+				}
+			qsort(buf, (size_t)at, sizeof *buf, cmp_i32);
+			int64_t distinct = 0;
+			for (int64_t k = 0; k < at; k++)
+				distinct += (k == 0 || buf[k] != buf[k - 1]);
+			lines += (double)distinct;
+			entries += (double)at;
+			free(buf);
+		}
+		free(inv);
+	}
+	*lines_out = lines;
+	*entries_out = entries;
+}
+
+/* positions of the non-hot items in key order behind the hot ones (list[0..nhot) by descending degree) */
+static int finish_perm(const int32_t *key, int64_t count, int64_t nkeys, const unsigned char *is_hot, const int32_t *list,
+		       int64_t nhot, int32_t *perm)
+{
+	int rc = sort_by_key(key, count, nkeys, perm);
+	if (rc != BLZ_OK || nhot <= 0)
+		return rc;
+	int32_t *order = malloc(sizeof *order * (size_t)count);
+	if (!order)
+		return blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
+	for (int64_t r = 0; r < count; r++)
+		order[perm[r]] = (int32_t)r;
+	int64_t at = nhot;
+	for (int64_t q = 0; q < count; q++)
+		if (!is_hot[order[q]])
+			perm[order[q]] = (int32_t)at++;
+	for (int64_t a = 0; a < nhot; a++)
+		perm[list[a]] = (int32_t)a;
+	free(order);
+	return BLZ_OK;
+}
+
+static int make_order(const blz_coo *M, int kind, unsigned char *const is_hot[2], int32_t *const list[2], const int64_t hot[2],
+		      int32_t *row_perm, int32_t *col_perm)
+{
+	const int64_t big = (M->nrows > M->ncols ? M->nrows : M->ncols) + 1;
+	int32_t *key = malloc(sizeof *key * (size_t)big);
+	double *sum = NULL;
+	int32_t *cnt = NULL;
+	int rc = key ? BLZ_OK : blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
+	if (rc == BLZ_OK && kind == ORD_BARYCENTRE) {
+		sum = malloc(sizeof *sum * (size_t)big);
+		cnt = malloc(sizeof *cnt * (size_t)big);
+		if (!sum || !cnt)
+			rc = blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
+	}
+	if (rc == BLZ_OK) {
+		if (kind == ORD_IDENTITY) {
+			for (int64_t r = 0; r < M->nrows; r++)
+				key[r] = (int32_t)r;
+			rc = finish_perm(key, M->nrows, M->nrows, is_hot[0], list[0], hot[0], row_perm);
+		} else if (kind == ORD_SMALLEST) {
+			for (int64_t r = 0; r < M->nrows; r++)
+				key[r] = (int32_t)M->ncols;
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
+			for (int64_t k = 0; k < M->nnz; k++)
+				if (!is_hot[1][M->j[k]])
+					atomic_min_i32(&key[M->i[k]], M->j[k]);
+			rc = finish_perm(key, M->nrows, M->ncols, is_hot[0], list[0], hot[0], row_perm);
+		} else {
+			memset(sum, 0, sizeof *sum * (size_t)M->nrows);
+			memset(cnt, 0, sizeof *cnt * (size_t)M->nrows);
+			for (int64_t k = 0; k < M->nnz; k++)
+				if (!is_hot[1][M->j[k]]) {
+					sum[M->i[k]] += (double)M->j[k];
+					cnt[M->i[k]]++;
+				}
+			for (int64_t r = 0; r < M->nrows; r++)
+				key[r] = cnt[r] ? (int32_t)(sum[r] / cnt[r]) : (int32_t)M->ncols;
+			rc = finish_perm(key, M->nrows, M->ncols, is_hot[0], list[0], hot[0], row_perm);
+		}
+	}
+	if (rc == BLZ_OK) {
+		if (kind == ORD_IDENTITY) {
+			for (int64_t c = 0; c < M->ncols; c++)
+				key[c] = (int32_t)c;
+			rc = finish_perm(key, M->ncols, M->ncols, is_hot[1], list[1], hot[1], col_perm);
+		} else if (kind == ORD_SMALLEST) {
+			for (int64_t c = 0; c < M->ncols; c++)
+				key[c] = (int32_t)M->nrows;
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
+			for (int64_t k = 0; k < M->nnz; k++)
+				if (!is_hot[0][M->i[k]])
+					atomic_min_i32(&key[M->j[k]], row_perm[M->i[k]]);
+			rc = finish_perm(key, M->ncols, M->nrows, is_hot[1], list[1], hot[1], col_perm);
+		} else {
+			memset(sum, 0, sizeof *sum * (size_t)M->ncols);
+			memset(cnt, 0, sizeof *cnt * (size_t)M->ncols);
+			for (int64_t k = 0; k < M->nnz; k++)
+				if (!is_hot[0][M->i[k]]) {
+					sum[M->j[k]] += (double)row_perm[M->i[k]];
+					cnt[M->j[k]]++;
+				}
+			for (int64_t c = 0; c < M->ncols; c++)
+				key[c] = cnt[c] ? (int32_t)(sum[c] / cnt[c]) : (int32_t)M->nrows;
+			rc = finish_perm(key, M->ncols, M->nrows, is_hot[1], list[1], hot[1], col_perm);
+		}
+	}
+	free(key);
+	free(sum);
+	free(cnt);
+	return rc;
+}
+
+int blz_reorder_auto(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int64_t hot[2], double min_share,
+		     double share[2], int rows_per_line, double locality[2], int *kind_out)
+{
+	if (!M || !row_perm || !col_perm || !hot || !share || !locality || rows_per_line < 1)
+		return blz_fail(BLZ_EINVAL, "blz_reorder_auto: bad argument");
+	locality[0] = locality[1] = 1.0;
+	if (kind_out)
+		*kind_out = ORD_SMALLEST;
+	if (M->nnz >= INT32_MAX || M->nnz == 0) {	/* entry numbers must fit an int32 here: keep round 1's order */
+		return blz_reorder_hot(M, row_perm, col_perm, hot, min_share, share);
+	}
+	const int64_t N[2] = { M->nrows, M->ncols };
+	const int64_t big = N[0] > N[1] ? N[0] : N[1];
+	int line_shift = 0;
+	while ((1 << (line_shift + 1)) <= rows_per_line)
+		line_shift++;
+	int32_t *deg = calloc((size_t)big + 1, sizeof *deg);
+	int32_t *list[2] = { NULL, NULL };
+	unsigned char *is_hot[2] = { calloc((size_t)N[0] + 1, 1), calloc((size_t)N[1] + 1, 1) };
+	int64_t *start[2] = { NULL, NULL };
+	int32_t *order[2] = { NULL, NULL };
+	int32_t *cand_r = malloc(sizeof *cand_r * (size_t)(N[0] ? N[0] : 1)), *cand_c = malloc(sizeof *cand_c * (size_t)(N[1] ? N[1] : 1));
+	int rc = (deg && is_hot[0] && is_hot[1] && cand_r && cand_c) ? BLZ_OK : blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
+	for (int sd = 0; sd < 2 && rc == BLZ_OK; sd++) {
+		const int32_t *idx = sd == 0 ? M->i : M->j;
+		memset(deg, 0, sizeof *deg * (size_t)(N[sd] + 1));
+		for (int64_t k = 0; k < M->nnz; k++)
+			deg[idx[k]]++;
+		list[sd] = malloc(sizeof(int32_t) * (size_t)(hot[sd] > 0 ? hot[sd] : 1));
+		if (!list[sd]) {
+			rc = blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
+			break;
+		}
+		int64_t held = 0;
+		int64_t got = pick_hot(deg, N[sd], hot[sd], list[sd], &held);
+		share[sd] = (double)held / (double)M->nnz;
+		if (share[sd] < min_share)
+			got = 0;
+		hot[sd] = got;
+		for (int64_t a = 0; a < got; a++)
+			is_hot[sd][list[sd][a]] = 1;
+		rc = group_entries(idx, N[sd], M->nnz, &start[sd], &order[sd]);
+	}
+	double best = -1.0;
+	for (int kind = 0; kind < ORD_KINDS && rc == BLZ_OK; kind++) {
+		if ((rc = make_order(M, kind, is_hot, list, hot, cand_r, cand_c)) != BLZ_OK)
+			break;
+		double ln[2], en[2];
+		/* product 0: rows of M gather block rows by column; product 1: rows of M^T (columns of M) gather by row */
+		score_product(N[0], cand_r, M->j, cand_c, start[0], order[0], line_shift, 4096, 48, is_hot[1], &ln[0], &en[0]);
+		score_product(N[1], cand_c, M->i, cand_r, start[1], order[1], line_shift, 4096, 48, is_hot[0], &ln[1], &en[1]);
+		const double tot = ln[0] + ln[1];
+		if (best < 0.0 || tot < best * 0.995) {	/* a later candidate must win by more than the sampling noise */
+			best = tot;
+			memcpy(row_perm, cand_r, sizeof *cand_r * (size_t)N[0]);
+			memcpy(col_perm, cand_c, sizeof *cand_c * (size_t)N[1]);
+			locality[0] = en[0] > 0.0 ? ln[0] / en[0] : 1.0;
+			locality[1] = en[1] > 0.0 ? ln[1] / en[1] : 1.0;
+			if (kind_out)
+				*kind_out = kind;
+		}
+	}
+	free(deg);
+	free(cand_r);
+	free(cand_c);
+	for (int sd = 0; sd < 2; sd++) {
+		free(list[sd]);
+		free(is_hot[sd]);
+		free(start[sd]);
+		free(order[sd]);
+	}
+	return rc;
+}
+
+/* Entries of every row in ascending column order (values follow): with the dense columns numbered first, a row's
+ * panel entries then come before its gathered ones, so the batches of a lane group are of one kind. */
+void blz_csr_sort_rows(blz_csr *A)
+{
+#pragma omp parallel for schedule(dynamic, 4096) if (A->nnz > 200000)
+	for (int64_t r = 0; r < A->rows; r++) {
+		const uint32_t k0 = A->row_ptr[r], k1 = A->row_ptr[r + 1];
+		for (uint32_t a = k0 + 1; a < k1; a++) {	/* insertion sort: rows are short or nearly sorted */
+			const int32_t c = A->col_idx[a];
+			const uint32_t v = A->val ? A->val[a] : 0;
+			uint32_t b = a;
+			while (b > k0 && A->col_idx[b - 1] > c) {
+				A->col_idx[b] = A->col_idx[b - 1];
+				if (A->val)
+					A->val[b] = A->val[b - 1];
+				b--;
+			}
+			A->col_idx[b] = c;
+			if (A->val)
+				A->val[b] = v;
+		}
+	}
 }
 
 int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, int chunks, blz_csr slabs[2], int64_t *bounds0,

@@ -54,6 +54,7 @@ def lib():
         L.blz_iterations.restype = C.c_int64
         L.blz_local_nnz.restype = C.c_int64
         L.blz_matrix_stream_bytes.restype = C.c_int64
+        L.blz_panel_rows.restype = C.c_int64
         L.blz_destroy.restype = None
         L.blz_coo_free.restype = None
         L.blz_csr_free.restype = None
@@ -112,6 +113,15 @@ class Matrix:
                                   C.c_int(int(pattern)), C.c_uint64(prime), C.byref(M)))
         return Matrix._take(M)
 
+    @staticmethod
+    def synth_structured(nrows, ncols, nnz, seed, prime, pattern=False, hot_pct=40, band_pct=30, band=4096):
+        """Heavy-tailed column degrees + banded supports (blz_synth_structured): the extra, non-headline workload."""
+        M = Coo()
+        check(lib().blz_synth_structured(C.c_int64(nrows), C.c_int64(ncols), C.c_int64(nnz), C.c_uint64(seed),
+                                         C.c_int(int(pattern)), C.c_uint64(prime), C.c_int(hot_pct), C.c_int(band_pct),
+                                         C.c_int64(band), C.byref(M)))
+        return Matrix._take(M)
+
     def save(self, path):
         check(lib().blz_mm_save_coo(path.encode(), C.byref(self.c)))
 
@@ -150,6 +160,30 @@ def shard_matrix(M, right, rank, nranks, chunks=1):
         out.append(dict(rows=int(A.rows), cols=int(A.cols), nnz=int(A.nnz), row_ptr=rp, col_idx=ci, val=va))
         lib().blz_csr_free(C.byref(A))
     return dict(slabs=out, bounds=[list(b0), list(b1)], stride=list(stride), chunks=chunks if nranks > 1 else 1)
+
+
+def reorder_hot(M, hot_rows, hot_cols, min_share=0.10):
+    """blz_reorder_hot(): (row_perm, col_perm, (rows taken, columns taken), (their shares of the entries))."""
+    rp = np.empty(M.nrows, dtype=np.int32)
+    cp = np.empty(M.ncols, dtype=np.int32)
+    hot = (C.c_int64 * 2)(hot_rows, hot_cols)
+    share = (C.c_double * 2)(0.0, 0.0)
+    check(lib().blz_reorder_hot(C.byref(M.c), rp.ctypes.data_as(C.POINTER(C.c_int32)), cp.ctypes.data_as(C.POINTER(C.c_int32)),
+                                hot, C.c_double(min_share), share))
+    return rp, cp, (int(hot[0]), int(hot[1])), (float(share[0]), float(share[1]))
+
+
+def reorder_auto(M, hot_rows=0, hot_cols=0, min_share=0.25, rows_per_line=2):
+    """blz_reorder_auto(): (row_perm, col_perm, hot taken, shares, (lines per entry M*x, M^T*x), order kind)."""
+    rp = np.empty(M.nrows, dtype=np.int32)
+    cp = np.empty(M.ncols, dtype=np.int32)
+    hot = (C.c_int64 * 2)(hot_rows, hot_cols)
+    share = (C.c_double * 2)(0.0, 0.0)
+    loc = (C.c_double * 2)(1.0, 1.0)
+    kind = C.c_int(0)
+    check(lib().blz_reorder_auto(C.byref(M.c), rp.ctypes.data_as(C.POINTER(C.c_int32)), cp.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 hot, C.c_double(min_share), share, C.c_int(rows_per_line), loc, C.byref(kind)))
+    return rp, cp, (int(hot[0]), int(hot[1])), (float(share[0]), float(share[1])), (float(loc[0]), float(loc[1])), int(kind.value)
 
 
 def reorder(M):
@@ -246,6 +280,19 @@ class Context:
 
     def matrix_stream_bytes(self, transpose):
         return int(lib().blz_matrix_stream_bytes(self.h, C.c_int(int(transpose))))
+
+    def locality(self):
+        """((lines per gathered entry of M*x, of M^T*x), order kind) as found by the renumbering (blz_locality)."""
+        loc = (C.c_double * 2)(1.0, 1.0)
+        kind = C.c_int(0)
+        check(lib().blz_locality(self.h, loc, C.byref(kind)))
+        return (float(loc[0]), float(loc[1])), int(kind.value)
+
+    def panel_rows(self, transpose):
+        """(block rows of the operand kept in LDS, share of the entries they serve) for M*x (False) / M^T*x (True)."""
+        share = C.c_double(0.0)
+        rows = int(lib().blz_panel_rows(self.h, C.c_int(int(transpose)), C.byref(share)))
+        return rows, float(share.value)
 
     def owner_of_row(self, block, row):
         return int(lib().blz_owner_of_row(self.h, C.c_int(block), C.c_int64(row)))

@@ -85,6 +85,14 @@ int blz_mm_save_coo(const char *path, const blz_coo *M);
 int blz_synth_coo(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int pattern,
 		  uint64_t prime, blz_coo *out);
 
+/* A synthetic matrix WITH structure (never the headline workload): hot_pct % of a row's entries are drawn with
+ * probability ~ 1/(c + 16) (heavy-tailed column degrees, dense columns first, as in a sieve relation matrix),
+ * band_pct % uniformly from a band of `band` columns centred on r * C / R (correlated supports of neighbouring
+ * rows), the rest uniformly.  Used to measure what the uniform stand-ins cannot show: the LDS-resident panel of
+ * dense block rows and the per-XCD row ranges of the SpMV. */
+int blz_synth_structured(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int pattern, uint64_t prime,
+			 int hot_pct, int band_pct, int64_t band, blz_coo *out);
+
 /* COO -> CSR of M (transpose=0) or of M^T (transpose=1); duplicates are kept (they add,
  * as in the reference's scatter loop :277-286).  pattern!=0 drops the value array when all
  * values are 1. */
@@ -102,6 +110,22 @@ int blz_partition_rows(const blz_csr *A, int parts, int64_t *bounds);
  * -5 % per iteration on the GL7d19-shape matrix, -9 % on the relat9 shape.
  * row_perm[r] / col_perm[c] = new index of row r / column c of M (arrays of nrows / ncols int32). */
 int blz_reorder(const blz_coo *M, int32_t *row_perm, int32_t *col_perm);
+
+/* blz_reorder with the densest rows / columns numbered first.  hot[0] (rows) and hot[1] (columns): in = the most a
+ * panel can hold, out = how many were taken (0 when they hold less than min_share of the entries); share[] = the
+ * fraction of the entries they hold.  The SpMV keeps the first hot[.] block rows of its operand in LDS. */
+int blz_reorder_hot(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int64_t hot[2], double min_share,
+		    double share[2]);
+/* The renumbering the solver uses: blz_reorder_hot's hot rows / columns in front, and behind them the best of three
+ * orders -- rows by smallest column (blz_reorder), the file's own order, rows by the mean of their columns -- judged on a
+ * sample of windows of 4096 consecutive rows of each product by the number of distinct 128-byte lines of the operand
+ * they touch (rows_per_line block rows share a line).  locality[t] = lines per gathered entry of product t (0: M * x,
+ * 1: M^T * x) under the chosen order; 1.0 means no reuse to be had.  *kind (may be NULL): 0 smallest, 1 file order,
+ * 2 mean. */
+int blz_reorder_auto(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int64_t hot[2], double min_share,
+		     double share[2], int rows_per_line, double locality[2], int *kind);
+/* entries of every row in ascending column order */
+void blz_csr_sort_rows(blz_csr *A);
 
 /* What rank `rank` of `nranks` keeps of M for the solve (right=0: x*M=0, right=1: M*x=0).
  * "Side 0" is the row space of v/Av/p, "side 1" that of tmp (sequential/lanczos_modp.c:592-593).
@@ -171,6 +195,18 @@ int blz_set_matrix(blz_ctx *ctx, const blz_coo *M, int right, int rank, int nran
  * and results are bit-identical either way.  With nranks > 1 a rank's slab is a set of original rows that need
  * not be contiguous; blz_owner_of_row tells which rank holds a given original row of a block. */
 int blz_owner_of_row(const blz_ctx *ctx, int block, int64_t row);
+
+/* Block rows of the operand of product `transpose` (0: M * x, 1: M^T * x) that the SpMV keeps in LDS: the densest
+ * columns (rows for the transpose) of a heavy-tailed matrix, numbered first by the solver's internal renumbering.
+ * 0 for matrices without such structure, with several ranks, or with BLZ_NO_PANEL=1.  *share (may be NULL) = the
+ * fraction of the entries those block rows serve. */
+int64_t blz_panel_rows(const blz_ctx *c, int transpose, double *share);
+
+/* What the renumbering found: locality[t] = distinct 128-byte lines of the operand per gathered entry in windows of 4096
+ * consecutive rows of product t (0: M * x, 1: M^T * x) -- 1.0 on a matrix without structure, lower when neighbouring
+ * rows share columns (the SpMV then walks per-XCD row ranges); *order_kind (may be NULL): 0 rows by smallest column,
+ * 1 the file's order, 2 rows by the mean of their columns. */
+int blz_locality(const blz_ctx *c, double locality[2], int *order_kind);
 
 int64_t blz_rows(const blz_ctx *ctx, int block);	/* global row count of a block (N or C) */
 /* size of this rank's slab of a block; *first = its first row in the SOLVER's numbering (see blz_owner_of_row) */

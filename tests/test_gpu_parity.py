@@ -386,3 +386,50 @@ def test_staged_matrix_stream_against_oracle(monkeypatch, n, p, kind, capw, rpg)
                 ctx.init_v()
                 ctx.iterate(3)
                 assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
+
+
+@pytest.mark.parametrize("n,p,kind", [(8, P61, "packed"), (4, 2147483647, "packed"), (16, P61, "ones"), (2, (1 << 62) - 57, "array"),
+                                      (1, 65537, "packed"), (32, 1073741789, "ones")])
+def test_panel_of_dense_block_rows_against_oracle(monkeypatch, n, p, kind):
+    """k_spmv_panel: on a matrix with heavy-tailed column degrees the solver numbers the densest columns (rows, for the
+    transposed product) first and the SpMV keeps that many block rows of its operand in LDS; entries outside the
+    panel are gathered as usual; rows are dealt to the XCDs in nnz-balanced ranges.  Both orientations of a structured
+    matrix and of its transpose (so that each product meets a panel), a full and a tiny panel, every value mode, the
+    plain and the fused-with-block_dot forms, against the oracle; BLZ_NO_PANEL=1 gives the same words."""
+    S = blz.Matrix.synth_structured(7000, 8000, 140000, 0x4E465331 + n, p, pattern=(kind == "ones"), hot_pct=45,
+                                    band_pct=25, band=512)
+    ii, jj, xx = S.i.copy(), S.j.copy(), S.x.copy()
+    if kind == "array":
+        rng = np.random.default_rng(n)
+        xx = (rng.integers(1, 2 ** 32, size=len(xx), dtype=np.uint64) % p).astype(np.uint32)
+    ii[:2500] = 5                                       # an outlier row as well
+    for transposed in (False, True):
+        M = blz.Matrix(8000, 7000, jj, ii, xx) if transposed else blz.Matrix(7000, 8000, ii, jj, xx)
+        Mo = as_orc(M)
+        for right in (False, True):
+            want = orc.block_lanczos(Mo, n, p, right=right, stop_after=3)
+            for env in ({"BLZ_NO_PANEL": "0"}, {"BLZ_NO_PANEL": "0", "BLZ_PANEL_ROWS": "37", "BLZ_PANEL_MIN_PCT": "1"},
+                        {"BLZ_NO_PANEL": "0", "BLZ_PANEL_STRIPES": "1"}, {"BLZ_NO_PANEL": "1"}):
+                for k_ in ("BLZ_PANEL_ROWS", "BLZ_PANEL_MIN_PCT", "BLZ_PANEL_STRIPES"):
+                    monkeypatch.delenv(k_, raising=False)
+                for k_, v_ in env.items():
+                    monkeypatch.setenv(k_, v_)
+                with blz.Context(p, n) as ctx:
+                    ctx.set_matrix(M, right)
+                    rows_a, share_a = ctx.panel_rows(False)
+                    rows_b, share_b = ctx.panel_rows(True)
+                    if env["BLZ_NO_PANEL"] == "1":
+                        assert rows_a == rows_b == 0
+                    else:
+                        assert (rows_b if transposed else rows_a) > 0 and max(share_a, share_b) > 0.01
+                    x = (np.arange(ctx.rows(blz.TMP) * n, dtype=np.uint64) * 2654435761) % p
+                    ctx.set_block(blz.TMP, x)
+                    ctx.spmv(right, blz.TMP, blz.AV)
+                    assert np.array_equal(ctx.get_block(blz.AV), orc.spmv(Mo, x, right, n, p))
+                    y = (np.arange(ctx.rows(blz.V) * n, dtype=np.uint64) * 40503 + 7) % p
+                    ctx.set_block(blz.V, y)
+                    ctx.spmv(not right, blz.V, blz.TMP)
+                    assert np.array_equal(ctx.get_block(blz.TMP), orc.spmv(Mo, y, not right, n, p))
+                    ctx.init_v()
+                    ctx.iterate(3)
+                    assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])

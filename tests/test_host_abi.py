@@ -202,3 +202,55 @@ def test_reorder_gives_permutations_sorted_by_smallest_neighbour(name):
     by_new = np.empty(M.ncols, dtype=np.int64)
     by_new[cp] = minrow
     assert (np.diff(by_new) >= 0).all()
+
+
+def test_structured_generator_and_hot_first_numbering():
+    """blz_synth_structured: heavy-tailed column degrees + banded supports (the extra, non-headline workload);
+    blz_reorder_hot numbers the densest rows / columns first when they hold enough of the entries and leaves a
+    uniform matrix to the plain locality order."""
+    p = (1 << 61) - 1
+    M = blz.Matrix.synth_structured(20000, 24000, 400000, 0x4E465331, p, hot_pct=40, band_pct=30, band=2048)
+    assert M.nnz == 400000 and int(M.i.max()) == 19999 and int(M.j.max()) < 24000
+    per_row = np.bincount(M.i, minlength=20000)
+    assert per_row.min() == per_row.max() == 20
+    for r in (0, 777, 19999):                        # distinct columns within a row
+        cols = M.j[M.i == r]
+        assert len(set(cols.tolist())) == len(cols)
+    deg = np.bincount(M.j, minlength=24000)
+    top = np.sort(deg)[::-1][:512].sum() / M.nnz
+    assert 0.2 < top < 0.5                           # ~ln(528/16)/ln(24016/16) * 0.4 of the entries in 512 columns
+    rp, cp, hot, share = blz.reorder_hot(M, 512, 512)
+    assert sorted(rp.tolist()) == list(range(20000)) and sorted(cp.tolist()) == list(range(24000))
+    assert hot[1] == 512 and abs(share[1] - top) < 1e-9
+    assert hot[0] == 0 and share[0] < 0.10           # rows all have 20 entries: nothing dense on that side
+    newdeg = np.empty_like(deg)
+    newdeg[cp] = deg
+    assert (np.diff(newdeg[:512]) <= 0).all()        # by descending degree
+    assert newdeg[:512].min() >= newdeg[512:].max()  # and every one of them at least as dense as the rest
+    U = blz.Matrix.synth(20000, 24000, 400000, 0x474C3764, p)
+    _, _, hot_u, share_u = blz.reorder_hot(U, 512, 512)
+    assert hot_u == (0, 0) and max(share_u) < 0.05
+
+
+def test_renumbering_is_chosen_by_the_lines_it_leaves_to_fetch():
+    """blz_reorder_auto scores three orders (rows by smallest column, the file's order, rows by the mean of their columns)
+    by the distinct 128-byte lines that windows of 4096 consecutive rows touch: a uniform matrix keeps round 1's order and
+    reports little reuse; a banded matrix keeps its own order (or the mean order) and
+    reports the reuse the SpMV's per-XCD row ranges then exploit."""
+    p = (1 << 61) - 1
+    U = blz.Matrix.synth(600000, 640000, 3000000, 0x474C3764, p)
+    rp, cp, hot, _, loc, kind = blz.reorder_auto(U)
+    assert np.array_equal(np.sort(rp), np.arange(600000)) and np.array_equal(np.sort(cp), np.arange(640000))
+    assert kind == 0 and hot == (0, 0) and min(loc) > 0.7       # the rows' first entries share lines under this order
+    rp0, cp0 = blz.reorder(U)
+    assert np.array_equal(rp, rp0) and np.array_equal(cp, cp0)          # exactly round 1's order
+    B = blz.Matrix.synth_structured(60000, 64000, 600000, 0x4E465331, p, hot_pct=0, band_pct=90, band=1024)
+    rp, cp, _, _, loc, kind = blz.reorder_auto(B)
+    assert kind in (1, 2) and max(loc) < 0.5
+    # rows shuffled inside blocks of 64 (a file that is only roughly ordered): the mean order (or the file's) still finds it
+    rng = np.random.default_rng(3)
+    pr = (np.arange(60000).reshape(-1, 64)[:, rng.permutation(64)] if False else
+          np.concatenate([b0 + rng.permutation(min(64, 60000 - b0)) for b0 in range(0, 60000, 64)])).astype(np.int32)
+    Bs = blz.Matrix(60000, 64000, pr[B.i], B.j, B.x)
+    rp_s, cp_s, _, _, loc_s, kind_s = blz.reorder_auto(Bs)
+    assert np.array_equal(np.sort(rp_s), np.arange(60000)) and kind_s in (1, 2) and max(loc_s) < 0.5
