@@ -6,19 +6,26 @@ two block SpMVs (tmp = M^T v, Av = M tmp), the n x n block inner products, the s
 row-local block update, all on the GPU with every operand resident in HBM before the clock starts.
 
   metric  = nnz*n mod-p MAC/s : (2 SpMV * nnz * n) * steps / time   (block products are NOT counted)
-  value   = whole-job rate over all ranks (strong scaling: the matrix is fixed, rows are partitioned)
+  value   = whole-job rate over all ranks (strong scaling: the matrix is fixed, rows are partitioned);
+            the timed region (exactly K steps between barrier + synchronize) is repeated 5 times and the
+            MEDIAN region is reported; every region's time is listed under "repeats"
   roofline= the SpMV kernel (dominant): algorithmic bytes of SURVEY 8(d) / mean launch duration measured
             with HIP events on the solver's stream inside this run, against the 8 TB/s HBM3E peak
-  cpu_baseline = the oracle's OpenMP kernels (restating openMP/lanczos_modp.c) timed on this box's
-            host cores on a bounded sample of the SAME workload; a reported baseline, not the target.
+  cpu_baseline = the oracle's by-rows OpenMP kernels timed on this box's host cores on a bounded sample of
+            the SAME workload, at 16 threads and at all cores; a reported baseline, not the target.
+  extra.workloads = the other single-GPU configs (relat9 and relat8 shapes) in the same line (N = 1 only)
+
+Real matrices: if $BLZ_MTX_DIR holds GL7d19.mtx / relat9.mtx / relat8.mtx they are loaded instead of the seeded
+synthetic stand-ins of the same shape ("data" says which).
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run, one
 process per GPU.  torch.distributed (gloo) carries only the control plane (RCCL id, barrier, max of the
-times); the data path's collectives are RCCL calls made by libblz_hip.so on its own stream.
+times, verdicts); the data path's collectives are RCCL calls made by libblz_hip.so on its own stream.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,11 +38,11 @@ P31 = (1 << 31) - 1
 # themselves are not on the box, so seeded synthetic stand-ins of the same shape are generated.
 WORKLOADS = {
     "gl7d19": dict(desc="JGD_GL7d/GL7d19-shape synthetic", rows=1911130, cols=1955309, nnz=37322725, prime=P61,
-                   n=8, right=False, seed=0x474C3764, pattern=False),
+                   n=8, right=False, seed=0x474C3764, pattern=False, mtx="GL7d19.mtx"),
     "relat9": dict(desc="JGD_Relat/relat9-shape synthetic", rows=12360060, cols=549336, nnz=38955420, prime=P61,
-                   n=8, right=True, seed=0x52454C39, pattern=False),
+                   n=8, right=True, seed=0x52454C39, pattern=False, mtx="relat9.mtx"),
     "relat8": dict(desc="JGD_Relat/relat8-shape synthetic", rows=345688, cols=12347, nnz=1334038, prime=P31,
-                   n=4, right=False, seed=0x52454C38, pattern=False),
+                   n=4, right=False, seed=0x52454C38, pattern=False, mtx="relat8.mtx"),
     # config 5 is 50M x 50M, 2e9 nnz over 8 GPUs; this is one GPU's quarter-scale share of it (same density 40/row,
     # all-ones pattern path, n=16, 128-byte block rows)
     "synth5q": dict(desc="config-5-shape synthetic at 1/4 linear scale (all-ones pattern)", rows=12500000, cols=12500000,
@@ -44,8 +51,8 @@ WORKLOADS = {
     "synth5": dict(desc="config-5 synthetic (all-ones pattern), full size on ONE GPU", rows=50000000, cols=50000000,
                    nnz=2000000000, prime=P61, n=16, right=False, seed=0x53594E35, pattern=True),
     # EXTRA workload, not a BASELINE config and never the headline: a matrix WITH structure (heavy-tailed column degrees,
-    # banded supports -- the shape of a sieve relation matrix), for what the uniform stand-ins cannot show: the LDS panel
-    # of dense block rows and the per-XCD row ranges of the SpMV
+    # banded supports -- the shape of a sieve relation matrix), for what the uniform stand-ins cannot show: the renumbering
+    # chosen by line footprint, the per-XCD row ranges and the LDS panel of the SpMV
     "nfs": dict(desc="EXTRA (not a BASELINE config): structured synthetic, 40 % of a row's entries ~1/(c+16), 30 % in a band "
                      "of 4096 columns, 30 % uniform", rows=2000000, cols=2000000, nnz=40000000, prime=P61, n=8, right=False,
                 seed=0x4E465331, pattern=False, structured=dict(hot_pct=40, band_pct=30, band=4096)),
@@ -53,6 +60,7 @@ WORKLOADS = {
                  n=8, right=False, seed=0x54494E59, pattern=False),
 }
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+REPEATS = 5             # timed regions of K steps each; the median one is reported
 
 
 def prime_name(p):
@@ -64,16 +72,136 @@ def spmv_alg_bytes(nnz, rows_out, rows_in, n, w, pattern):
     return nnz * (4 + (0 if pattern else 4)) + 4 * (rows_out + 1) + (rows_in + rows_out) * n * w
 
 
+def make_matrix(blz, w, p):
+    """The workload's matrix: the real file when $BLZ_MTX_DIR has it, else the seeded synthetic of the same shape."""
+    mdir = os.environ.get("BLZ_MTX_DIR")
+    if mdir and w.get("mtx") and os.path.exists(os.path.join(mdir, w["mtx"])):
+        path = os.path.join(mdir, w["mtx"])
+        return blz.Matrix.load(path, p), f"real: {path}"
+    if w.get("structured"):
+        return (blz.Matrix.synth_structured(w["rows"], w["cols"], w["nnz"], w["seed"], p, pattern=w["pattern"], **w["structured"]),
+                "synthetic")
+    return blz.Matrix.synth(w["rows"], w["cols"], w["nnz"], w["seed"], p, pattern=w["pattern"]), "synthetic"
+
+
+class Stopped(Exception):
+    pass
+
+
+def measure(blz, torch, dist, ctx, info, w, steps, warmup, repeats):
+    """Warm up, time `repeats` regions of exactly `steps` steps (barrier + synchronize on both sides, MAX over ranks),
+    then the same steps once more with HIP-event spans per kernel class.  Returns the numbers of one workload."""
+    n, right = w["n"], w["right"]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def all_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    bad = [0.0]
+
+    def run(k):
+        done, stopped, dev_ms = ctx.iterate(k)
+        if stopped or done != k:
+            bad[0] = 1.0
+        return dev_ms
+
+    def check():
+        # every rank takes the same decision (outside the timed regions): a solve that terminated early is no benchmark
+        if all_max(bad[0]) > 0:
+            raise Stopped("the solve terminated inside the measured steps; use a larger workload")
+
+    if warmup > 0:
+        run(warmup)
+    check()
+    times, dev = [], []
+    for _ in range(repeats):
+        ctx.sync()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        dev_ms = run(steps)
+        ctx.sync()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        times.append(all_max(elapsed))
+        dev.append(dev_ms)
+    check()
+    elapsed = statistics.median(times)
+
+    ctx.profile(True)
+    run(steps)
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    check()
+
+    word = ctx.word_bytes
+    rows_v, rows_t = ctx.rows(blz.V), ctx.rows(blz.TMP)
+    _, loc_v = ctx.local_rows(blz.V)
+    _, loc_t = ctx.local_rows(blz.TMP)
+    # per-rank algorithmic bytes of the two SpMV launches (X is read whole by every rank)
+    nnz1, nnz2 = ctx.local_nnz(not right), ctx.local_nnz(right)   # tmp = (right ? M : M^T) v, then Av = the other one
+    pattern = info["pattern"]
+    bytes1 = spmv_alg_bytes(nnz1, loc_t, rows_v, n, word, pattern)
+    bytes2 = spmv_alg_bytes(nnz2, loc_v, rows_t, n, word, pattern)
+    kernels = {k: dict(ms_mean=(v["ms_total"] / steps) if v["launches"] else None, launches=v["launches"])
+               for k, v in prof.items()}     # ms_mean = per step (a step may issue several launches of one class)
+    kernels["spmv1"]["alg_bytes"] = bytes1
+    kernels["spmv2"]["alg_bytes"] = bytes2
+    for k_ in ("spmv1", "spmv2"):
+        if kernels[k_]["ms_mean"]:
+            kernels[k_]["alg_GBps"] = kernels[k_]["alg_bytes"] / (kernels[k_]["ms_mean"] * 1e-3) / 1e9
+    kernels["block_dot"]["alg_bytes"] = 2 * loc_v * n * word
+    kernels["orthogonalize"]["alg_bytes"] = 5 * loc_v * n * word
+    t_spmv_ms = prof["spmv1"]["ms_total"] / max(steps, 1)
+    macs_per_step = 2 * info["nnz"] * n
+    loc, kind = ctx.locality()
+    return dict(elapsed=elapsed, times=times, device_ms_per_step=statistics.median(dev) / steps, kernels=kernels,
+                t_spmv_ms=t_spmv_ms, alg_bytes=bytes1, achieved=bytes1 / (t_spmv_ms * 1e-3) / 1e9, nnz1=nnz1,
+                macs_per_step=macs_per_step, value=macs_per_step * steps / elapsed, word=word, rows_v=rows_v, rows_t=rows_t,
+                renumbering=dict(lines_per_entry=dict(M=loc[0], Mt=loc[1]), order=("smallest", "file", "mean")[kind]),
+                lds_panel={"spmv1": dict(zip(("rows", "share"), ctx.panel_rows(not right))),
+                           "spmv2": dict(zip(("rows", "share"), ctx.panel_rows(right)))})
+
+
+def spmv_traffic(workload, world):
+    """HBM-side traffic of the first SpMV's kernel from the committed rocprofv3 PMC passes of this same command
+    (tools/gpu_profile.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs; bench.py cannot collect PMCs itself)."""
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{workload}_n{world}.json")
+    if not os.path.exists(tpath):
+        return None, None
+    for name, rec in json.load(open(tpath)).items():
+        plain = name.startswith("k_spmv<") or (name.startswith("k_spmv_staged<") and ", false," in name) \
+            or (name.startswith("k_spmv_panel<") and ", false," in name)
+        if plain and "FETCH_SIZE_bytes_per_launch" in rec and "WRITE_SIZE_bytes_per_launch" in rec:
+            # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE = TCC_EA0_RDREQ x 64 B although every request is a
+            # 128-byte line fill, so it is doubled; WRITE_SIZE is exact.  profiles/r01_v6_gl7d19_pmc_l2_fabric.txt and
+            # profiles/r02_ubench2_pmc.txt confirm it: every L2->fabric read request of a gather is tallied under
+            # TCC_EA0_RDREQ_128B, whatever the allocation kind or load policy.
+            return 2 * rec["FETCH_SIZE_bytes_per_launch"] + rec["WRITE_SIZE_bytes_per_launch"], os.path.relpath(tpath, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="gl7d19", choices=sorted(WORKLOADS))
+    ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps; the median is reported")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = 16 threads and all cores, else this many only")
     ap.add_argument("--ref-iterations", type=int, default=50,
                     help="iterations of the unmodified reference OpenMP binary on a 1/4-scale sample (0 = skip)")
+    ap.add_argument("--extras", type=int, default=-1,
+                    help="1/0: also run the other single-GPU configs (relat9, relat8); default: only with the default workload at N=1")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): RCCL and gloo print banners to fd 1 from native code, so fd 1 is
@@ -110,13 +238,31 @@ def main():
     local_rank %= blz.device_count()
     torch.cuda.set_device(local_rank)
 
+    def leave(code, msg):
+        """every rank leaves together (a lone sys.exit would leave the others in a barrier until the gloo timeout)"""
+        print(f"bench.py: {msg}", file=sys.stderr)
+        if dist is not None:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        sys.exit(code)
+
     w = WORKLOADS[args.workload]
     p, n, right = w["prime"], w["n"], w["right"]
     t0 = time.time()
-    if w.get("structured"):
-        M = blz.Matrix.synth_structured(w["rows"], w["cols"], w["nnz"], w["seed"], p, pattern=w["pattern"], **w["structured"])
-    else:
-        M = blz.Matrix.synth(w["rows"], w["cols"], w["nnz"], w["seed"], p, pattern=w["pattern"])
+    # Only rank 0 holds the matrix: it does the rank-independent set-up once (renumbering, CSR(M), CSR(M^T), partition) and
+    # shares it through a cache file that the other ranks map (one copy of the pages per node); every rank then uploads
+    # its own slabs.  Round 1 generated, renumbered and built the whole matrix in every process.
+    M, data, info = None, None, None
+    if rank == 0:
+        M, data = make_matrix(blz, w, p)
+        info = dict(nrows=M.nrows, ncols=M.ncols, nnz=M.nnz, pattern=bool((M.x == 1).all()), data=data)
+    if dist is not None:
+        box = [info]
+        dist.broadcast_object_list(box, src=0)
+        info = box[0]
+        data = info["data"]
     t_gen = time.time() - t0
 
     ctx = blz.Context(p, n, device=local_rank)
@@ -125,161 +271,127 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
     t0 = time.time()
-    ctx.set_matrix(M, right, rank, world)
+    if world == 1:
+        ctx.set_matrix(M, right, 0, 1)
+    else:
+        import tempfile
+        cache = os.path.join(tempfile.gettempdir(), f"blz_bench_{os.environ.get('MASTER_PORT', '0')}_{args.workload}_{world}.blzcache")
+        key = 0x42454E43 ^ (world << 40) ^ info["nnz"]
+        if rank == 0:
+            with blz.Prepared.prepare_for(ctx, M, right, world) as P:
+                P.save(cache, key)
+                dist.barrier()
+                ctx.set_matrix_prepared(P, rank)
+        else:
+            dist.barrier()
+            with blz.Prepared.load(cache, key) as P:
+                ctx.set_matrix_prepared(P, rank)
+        dist.barrier()
+        if rank == 0:
+            os.unlink(cache)
     ctx.init_v()
     ctx.sync()
     t_setup = time.time() - t0
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    # ---- warmup, then EXACTLY K steps between barrier + synchronize on both sides -------------
-    if args.warmup > 0:
-        ctx.iterate(args.warmup)
-    ctx.sync()
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    done, stopped, dev_ms = ctx.iterate(args.steps)
-    ctx.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    if stopped or done != args.steps:
-        sys.exit(f"bench.py: the solve terminated after {done} of {args.steps} steps; use a larger workload")
-
-    # ---- per-kernel durations with HIP events on the solver's stream, same K steps again ---------
-    ctx.profile(True)
-    ctx.iterate(args.steps)
-    prof = ctx.profile_read()
-    ctx.profile(False)
-
-    word = ctx.word_bytes
-    rows_v, rows_t = ctx.rows(blz.V), ctx.rows(blz.TMP)
-    _, loc_v = ctx.local_rows(blz.V)
-    _, loc_t = ctx.local_rows(blz.TMP)
-    # per-rank algorithmic bytes of the two SpMV launches (X is read whole by every rank)
-    nnz1, nnz2 = ctx.local_nnz(not right), ctx.local_nnz(right)   # tmp = (right ? M : M^T) v, then Av = the other one
-    pattern = bool((M.x == 1).all())
-    bytes1 = spmv_alg_bytes(nnz1, loc_t, rows_v, n, word, pattern)
-    bytes2 = spmv_alg_bytes(nnz2, loc_v, rows_t, n, word, pattern)
-    # roofline kernel = k_spmv, the first SpMV of every step (the second one carries block_dot as its epilogue and is
-    # listed under "kernels"); HIP-event spans on the solver's stream, collected inside blz_iterate
-    # (with several ranks a product is cut into column pieces that overlap the exchange: time per product, not per piece)
-    t_spmv_ms = prof["spmv1"]["ms_total"] / max(args.steps, 1)
-    alg_bytes = bytes1
-    achieved = alg_bytes / (t_spmv_ms * 1e-3) / 1e9
-    kernels = {k: dict(ms_mean=(v["ms_total"] / args.steps) if v["launches"] else None, launches=v["launches"])
-               for k, v in prof.items()}     # ms_mean = per step (a step may issue several launches of one class)
-    kernels["spmv1"]["alg_bytes"] = bytes1
-    kernels["spmv2"]["alg_bytes"] = bytes2
-    for k_ in ("spmv1", "spmv2"):
-        if kernels[k_]["ms_mean"]:
-            kernels[k_]["alg_GBps"] = kernels[k_]["alg_bytes"] / (kernels[k_]["ms_mean"] * 1e-3) / 1e9
-    kernels["block_dot"]["alg_bytes"] = 2 * loc_v * n * word
-    kernels["orthogonalize"]["alg_bytes"] = 5 * loc_v * n * word
-
-    # HBM-side traffic of the SpMV kernel from the committed rocprofv3 PMC passes of this same command
-    # (tools/gpu_profile.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs; bench.py cannot collect PMCs itself).
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}_n{world}.json")
-    if os.path.exists(tpath):
-        for name, rec in json.load(open(tpath)).items():
-            if name.startswith("k_spmv<") and "FETCH_SIZE_bytes_per_launch" in rec and "WRITE_SIZE_bytes_per_launch" in rec:
-                # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE = TCC_EA0_RDREQ x 64 B although every request
-                # is a 128-byte line fill, so it is doubled; WRITE_SIZE is exact.  The separate pass in
-                # profiles/r01_v6_gl7d19_pmc_l2_fabric.txt confirms it for this kernel: all of its 35.7 M L2->fabric
-                # read requests per launch are counted under TCC_EA0_RDREQ_128B -- a gathered 64-byte block row costs a
-                # whole 128-byte line.
-                traffic = 2 * rec["FETCH_SIZE_bytes_per_launch"] + rec["WRITE_SIZE_bytes_per_launch"]
-                traffic_src = os.path.relpath(tpath, ROOT)
-
-    macs_per_step = 2 * M.nnz * n
-    value = macs_per_step * args.steps / elapsed
+    try:
+        r = measure(blz, torch, dist, ctx, info, w, args.steps, args.warmup, max(1, args.repeats))
+    except Stopped as exc:
+        leave(1, str(exc))
+    traffic, traffic_src = spmv_traffic(args.workload, world)
+    t_spmv_ms = r["t_spmv_ms"]
 
     out = {
         "metric": "nnz*n mod-p MAC/s",
-        "value": value,
+        "value": r["value"],
         "unit": "MAC/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": r["elapsed"] / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "u64" if word == 8 else "u32",
-        "data": "synthetic",
+        "dtype": "u64" if r["word"] == 8 else "u32",
+        "data": data,
         "config": {
-            "workload": f"{w['desc']}: {w['rows']}x{w['cols']}, {M.nnz} nnz, --prime {prime_name(p)} --n {n} "
+            "workload": f"{w['desc']}: {info['nrows']}x{info['ncols']}, {info['nnz']} nnz, --prime {prime_name(p)} --n {n} "
                         f"{'--right' if right else '--left'}",
             "step": "one block-Lanczos iteration: 2 block SpMV + block_dot + semi_inverse + orthogonalize",
             "parallelism": "single GPU" if world == 1 else f"row-partition x{world} + RCCL all-gather/all-reduce",
-            "matrix": ("seeded synthetic WITH structure (extra workload)" if w.get("structured") else
-                       "seeded synthetic, uniform columns (SURVEY 8(d)); real .mtx not on the box"),
+            "matrix": (data if data != "synthetic" else
+                       ("seeded synthetic WITH structure (extra workload)" if w.get("structured") else
+                        "seeded synthetic, uniform columns (SURVEY 8(d)); real .mtx not on the box")),
+            "timing": f"median of {len(r['times'])} regions of {args.steps} steps each, max over ranks per region",
         },
+        "repeats": {"ms_per_step": [t / args.steps * 1e3 for t in r["times"]]},
         "roofline": {
-            "kernel": "k_spmv (first SpMV of each step: tmp = M^T v)",
+            "kernel": "the first SpMV of each step (tmp = M^T v): k_spmv, or k_spmv_staged / k_spmv_panel where the slab's plan chose them",
             "bound": "hbm",
-            "achieved": achieved,
+            "achieved": r["achieved"],
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
+            "frac": r["achieved"] / HBM_PEAK_GBPS,
             "traffic": traffic,
             "traffic_source": traffic_src,
             # the same launch measured in bytes that actually cross the L2 <-> fabric boundary
             "traffic_GBps": (traffic / (t_spmv_ms * 1e-3) / 1e9) if (traffic and t_spmv_ms) else None,
             "traffic_frac_of_peak": (traffic / (t_spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and t_spmv_ms) else None,
-            "alg_bytes_per_launch": alg_bytes,
+            "alg_bytes_per_launch": r["alg_bytes"],
             "ms_per_launch": t_spmv_ms,
-            # what this kernel is actually limited by: one 128-byte line fill per entry; the
-            # micro-benchmarked ceiling for random block-row gathers on MI355X is 54.7 G rows/s whatever the row
-            # size up to 128 B (profiles/r01_ubench_alu_and_gather.txt) = 7.0 TB/s of line traffic
-            "gathers_per_s": nnz1 / (t_spmv_ms * 1e-3) if t_spmv_ms else None,
-            "gather_ceiling_per_s": 54.7e9,
+            # what this kernel is actually limited by: one 128-byte line fill per gathered block row;
+            # the micro-benchmarked ceiling for random block-row gathers on MI355X is ~55 G rows/s whatever the row size
+            # up to 128 B, the allocation kind or the load policy (profiles/r02_ubench2_*) = 7.0 TB/s of line traffic
+            "gathers_per_s": r["nnz1"] / (t_spmv_ms * 1e-3) if t_spmv_ms else None,
+            "gather_ceiling_per_s": 55e9,
         },
-        "device_ms_per_step": dev_ms / args.steps,
-        "kernels": kernels,
-        "setup_s": {"generate": t_gen, "csr_upload_init": t_setup},
-        # block rows of each product's operand kept in LDS and the share of the entries they serve (0 on uniform matrices)
-        "renumbering": dict(zip(("lines_per_entry", "order"), (lambda l, k: (dict(zip(("M", "Mt"), l)), ("smallest", "file", "mean")[k]))(*ctx.locality()))),
-        "lds_panel": {"spmv1": dict(zip(("rows", "share"), ctx.panel_rows(not right))),
-                      "spmv2": dict(zip(("rows", "share"), ctx.panel_rows(right)))},
+        "device_ms_per_step": r["device_ms_per_step"],
+        "kernels": r["kernels"],
+        "setup_s": {"generate_or_load": t_gen, "csr_upload_init": t_setup,
+                    "note": "rank 0 prepares once and shares the result through an mmapped cache file when N > 1"},
+        "renumbering": r["renumbering"],
+        "lds_panel": r["lds_panel"],
     }
+    macs_per_step, rows_v, rows_t = r["macs_per_step"], r["rows_v"], r["rows_t"]
 
     # ---- CPU baseline on this box's host cores: bounded sample of the same workload ------------
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as orc
-        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        ncpu = os.cpu_count() or 1
+        thread_sets = [args.cpu_threads] if args.cpu_threads else sorted({min(16, ncpu), ncpu})
         Mo = orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+        pair = orc.CsrPair(Mo)                       # built once, outside the timed sample (as the GPU's CSR slabs are)
         big = max(rows_v, rows_t) * n
-        v = orc.init_v(rows_v, n, p)
-        tmp, Av, pb = np.zeros(big, np.uint64), np.zeros(rows_v * n, np.uint64), np.zeros(rows_v * n, np.uint64)
-        its, t_cpu = 0, 0.0
-        while True:
-            t0 = time.perf_counter()
-            orc.iteration_omp(Mo, n, p, right, v, tmp, Av, pb, threads)
-            dt = time.perf_counter() - t0
-            its += 1
-            t_cpu += dt
-            if t_cpu + dt > args.cpu_seconds or its >= args.steps:
-                break
+        runs, v = [], None
+        for threads in thread_sets:
+            v = orc.init_v(rows_v, n, p)
+            tmp, Av, pb = np.zeros(big, np.uint64), np.zeros(rows_v * n, np.uint64), np.zeros(rows_v * n, np.uint64)
+            its, t_cpu, budget = 0, 0.0, args.cpu_seconds / len(thread_sets)
+            while True:
+                t0 = time.perf_counter()
+                pair.iteration(n, p, right, v, tmp, Av, pb, threads)
+                dt = time.perf_counter() - t0
+                its += 1
+                t_cpu += dt
+                if t_cpu + dt > budget or its >= args.steps:
+                    break
+            runs.append(dict(cores=threads, value=macs_per_step * its / t_cpu, s_per_iteration=t_cpu / its, iterations=its))
+        pair.close()
+        best = max(runs, key=lambda q: q["value"])
         out["cpu_baseline"] = {
-            "value": macs_per_step * its / t_cpu,
+            "value": best["value"],
             "unit": "MAC/s",
-            "cores": threads,
+            "cores": best["cores"],
             "kind": "port",
-            "sample": f"{its} full iteration(s) of the same workload with the oracle's OpenMP kernels "
-                      f"(strategy of openMP/lanczos_modp.c, 128-bit sums), {t_cpu:.1f} s on {os.cpu_count()} host CPUs",
-            "s_per_iteration": t_cpu / its,
+            "sample": f"{best['iterations']} full iteration(s) of the same workload with the oracle's by-rows OpenMP kernels "
+                      f"(CSR built once, 128-bit sums; restating openMP/lanczos_modp.c with the output rows as the parallel "
+                      f"loop), {best['s_per_iteration'] * best['iterations']:.1f} s on {ncpu} host CPUs; the better of "
+                      f"{[q['cores'] for q in runs]} threads",
+            "s_per_iteration": best["s_per_iteration"],
+            "runs": runs,
         }
-        # the CPU's first iteration must equal the GPU's first iteration (same seed, same matrix)
+        # the CPU's iterations must equal the GPU's (same seed, same matrix): compare after the last sample
+        its = runs[-1]["iterations"]
         chk = blz.Context(p, n, device=local_rank)
         chk.set_matrix(M, right)
         chk.init_v()
@@ -288,7 +400,7 @@ def main():
         chk.close()
         out["cpu_baseline"]["gpu_equals_cpu_after_sample"] = same
         if not same:
-            sys.exit("bench.py: GPU and CPU baseline disagree after the sampled iterations")
+            leave(1, "GPU and CPU baseline disagree after the sampled iterations")
 
     # ---- the reference's own OpenMP program (oracle/_ref, compiled from its sources) on this box's host cores.
     # It cannot run the benchmark's configuration (p is capped at 2^30-35, u32 words, its u64 sums overflow on large
@@ -311,9 +423,9 @@ def main():
             if right:
                 cmd.append("--right")
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=td, timeout=240)
-                mt = re.search(r"Terminated in ([0-9.]+)s after (\d+) iterations", r.stdout)
-                if r.returncode == 0 and mt and float(mt.group(1)) > 0:
+                rr = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=td, timeout=240)
+                mt = re.search(r"Terminated in ([0-9.]+)s after (\d+) iterations", rr.stdout)
+                if rr.returncode == 0 and mt and float(mt.group(1)) > 0:
                     t_ref, k_ref = float(mt.group(1)), int(mt.group(2))
                     out["cpu_reference"] = {
                         "value": 2 * S.nnz * n * k_ref / t_ref, "unit": "MAC/s", "cores": threads, "kind": "reference",
@@ -322,13 +434,15 @@ def main():
                                   f"{t_ref:.1f} s main loop",
                         "s_per_iteration": t_ref / max(k_ref, 1)}
                 else:
-                    out["cpu_reference"] = {"error": (r.stderr or r.stdout)[-300:]}
+                    out["cpu_reference"] = {"error": (rr.stderr or rr.stdout)[-300:]}
             except Exception as exc:   # the reference is a reported extra, never a reason to lose the bench line
                 out["cpu_reference"] = {"error": repr(exc)}
 
     # ---- several ranks (or the exchange code forced on one): the sharded run must hold the same block as one GPU
     # solving the whole system.  Every rank sums the words of its slab of v; rank 0 repeats the same number of
-    # iterations on a plain single-GPU context (tens of milliseconds) and compares the totals mod 2^64.
+    # iterations on a plain single-GPU context (tens of milliseconds) and compares the totals mod 2^64.  The verdict is
+    # broadcast: on a mismatch the line carries value = null and EVERY rank exits non-zero.
+    verdict = 1
     if dist is not None:
         iters_done = ctx.iterations
         mine = int(ctx.get_block(blz.V).sum(dtype=np.uint64))          # rows of other ranks are left at zero
@@ -349,16 +463,51 @@ def main():
             os.environ.update(saved)
             out["sharded_equals_single_gpu"] = {"equal": same, "iterations": iters_done,
                                                 "check": "sum of the words of v mod 2^64, all ranks, vs one GPU on the whole matrix"}
-            if not same:
-                print("bench.py: WARNING the sharded run and the single-GPU run disagree", file=sys.stderr)
+            verdict = 1 if same else 0
+        vt = torch.tensor([verdict], dtype=torch.int64)
+        dist.broadcast(vt, src=0)
+        verdict = int(vt.item())
+        if not verdict and rank == 0:
+            out["value"] = None
+            out["invalid"] = "the sharded run and the single-GPU run of the same system disagree"
 
     ctx.close()
+    del M
+
+    # ---- the other single-GPU configs in the same line (default run at N = 1): relat9 shape (config 3) and relat8
+    # shape (config 2), same measurement, fewer regions
+    want_extras = (args.extras == 1) or (args.extras < 0 and args.workload == "gl7d19" and world == 1 and dist is None)
+    if want_extras and verdict:
+        out["extra"] = {"workloads": {}}
+        for name in ("relat9", "relat8"):
+            we = WORKLOADS[name]
+            try:
+                Me, data_e = make_matrix(blz, we, we["prime"])
+                ce = blz.Context(we["prime"], we["n"], device=local_rank)
+                ce.set_matrix(Me, we["right"])
+                ce.init_v()
+                re_ = measure(blz, torch, None, ce, dict(nnz=Me.nnz, pattern=bool((Me.x == 1).all())), we, args.steps, args.warmup, 3)
+                ce.close()
+                out["extra"]["workloads"][name] = {
+                    "workload": f"{we['desc']}: {Me.nrows}x{Me.ncols}, {Me.nnz} nnz, --prime {prime_name(we['prime'])} --n {we['n']} "
+                                f"{'--right' if we['right'] else '--left'}",
+                    "data": data_e, "value": re_["value"], "unit": "MAC/s", "ms_per_step": re_["elapsed"] / args.steps * 1e3,
+                    "roofline_frac": re_["achieved"] / HBM_PEAK_GBPS, "spmv1_GBps": re_["achieved"],
+                    "spmv1_ms": re_["t_spmv_ms"], "gathers_per_s": re_["nnz1"] / (re_["t_spmv_ms"] * 1e-3),
+                    "kernels_ms": {k_: v_["ms_mean"] for k_, v_ in re_["kernels"].items() if v_["ms_mean"]},
+                }
+                del Me
+            except Exception as exc:    # an extra never costs the headline line
+                out["extra"]["workloads"][name] = {"error": repr(exc)}
+
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not verdict:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

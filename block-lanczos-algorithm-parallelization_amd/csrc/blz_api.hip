@@ -116,6 +116,7 @@ struct blz_ctx {
 	hipEvent_t ev_prod = nullptr;			/* the producer of the block to exchange has been enqueued */
 	std::vector<hipEvent_t> ev_piece;		/* piece k of the exchange has landed */
 	u64 *small = nullptr, *partial = nullptr;
+	u64 *dot_send = nullptr;	/* this rank's vtAv | vtAAv before the all-reduce (several ranks): 2 n^2 words */
 	int max_dot_blocks = 0;
 	DevCtl *ctl = nullptr;
 	DevCtl host_ctl{};
@@ -130,6 +131,13 @@ struct blz_ctx {
 	hipGraphExec_t iter_graph = nullptr;
 	bool external_exchange = false;
 	bool force_comm = false;	/* BLZ_FORCE_COMM=1: issue the collectives even on one rank (plumbing test) */
+	/* asynchronous snapshot of v and p (checkpoints): pinned staging, its own stream, one in flight */
+	hipStream_t cstream = nullptr;
+	hipEvent_t ev_snap_go = nullptr, ev_snap_done = nullptr;
+	void *snap_host[2] = { nullptr, nullptr };
+	size_t snap_bytes = 0;
+	bool snap_pending = false;
+	int64_t snap_iterations = 0;
 	double hot_share[2] = { 0.0, 0.0 };	/* share of the entries held by the rows / columns numbered first */
 	double locality[2] = { 1.0, 1.0 };	/* lines per gathered entry in windows of rows, product M*x / M^T*x */
 	int order_kind = 0;			/* which order blz_reorder_auto chose */
@@ -263,6 +271,8 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	HIPCHK(hipEventCreate(&c->ev1));
 	HIPCHK(hipMalloc(&c->small, small_words(np_) * sizeof(u64)));
 	HIPCHK(hipMemset(c->small, 0, small_words(np_) * sizeof(u64)));
+	HIPCHK(hipMalloc(&c->dot_send, (size_t)2 * np_ * np_ * sizeof(u64)));
+	HIPCHK(hipMemset(c->dot_send, 0, (size_t)2 * np_ * np_ * sizeof(u64)));
 	/* partial rows of the inner products: the fused path (n <= 8) needs room for the streaming kernel plus the
 	 * outlier launches; the stand-alone kernel keeps the grid it was tuned with */
 	c->max_dot_blocks = c->cfg.num_cu * (np_ <= 8 ? 16 : 8);
@@ -303,7 +313,16 @@ extern "C" void blz_destroy(blz_ctx *c)
 		hipEventDestroy(e);
 	if (c->ev_prod) hipEventDestroy(c->ev_prod);
 	if (c->xstream) hipStreamDestroy(c->xstream);
+	if (c->cstream) {
+		hipStreamSynchronize(c->cstream);
+		hipStreamDestroy(c->cstream);
+	}
+	if (c->ev_snap_go) hipEventDestroy(c->ev_snap_go);
+	if (c->ev_snap_done) hipEventDestroy(c->ev_snap_done);
+	for (void *&h : c->snap_host)
+		if (h) hipHostFree(h);
 	if (c->small) hipFree(c->small);
+	if (c->dot_send) hipFree(c->dot_send);
 	if (c->partial) hipFree(c->partial);
 	if (c->ctl) hipFree(c->ctl);
 	if (c->ev0) hipEventDestroy(c->ev0);
@@ -419,139 +438,161 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D, int64_t hot_rows 
 	return BLZ_OK;
 }
 
-extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank, int nranks)
-{
-	if (!c || !M)
-		return blz_fail(BLZ_EINVAL, "blz_set_matrix: NULL argument");
-	if (nranks < 1 || rank < 0 || rank >= nranks)
-		return blz_fail(BLZ_EINVAL, "blz_set_matrix: rank %d of %d", rank, nranks);
-	if (nranks > 1 && (unsigned __int128)nranks * c->prime > ((unsigned __int128)1 << 64))
-		return blz_fail(BLZ_EINVAL, "nranks * p must not exceed 2**64 (u64 all-reduce of residues)");
-	HIPCHK(hipSetDevice(c->device));
-	if (c->iter_graph) {
-		hipGraphExecDestroy(c->iter_graph);
-		c->iter_graph = nullptr;
-	}
-	c->right = right ? 1 : 0;
-	c->rank = rank;
-	c->nranks = nranks;
-	/* side 0 = rows of v: rows of M for a left kernel, columns of M for a right kernel
-	 * (sequential/lanczos_modp.c:592-593). */
-	c->glob_rows[0] = right ? M->ncols : M->nrows;
-	c->glob_rows[1] = right ? M->nrows : M->ncols;
-	c->row_side[0] = right ? 1 : 0;		/* rows of M   */
-	c->row_side[1] = right ? 0 : 1;		/* rows of M^T */
+/* the parameters a context wants its matrix prepared with (pieces per exchange, renumbering, panel capacity) */
+struct PrepParams {
+	int K, reorder, rows_per_line;
+	int64_t hot_cap;
+	double min_share;
+};
 
-	blz_csr slabs[2];
+static PrepParams prep_params(const blz_ctx *c, int64_t mrows, int64_t mcols, int64_t nnz, int nranks)
+{
+	PrepParams q;
 	/* Pieces per exchange.  BLZ_AG_CHUNKS fixes it; otherwise up to 4 pieces of at least ~2 MB of the smaller
 	 * block's slab (below that the collectives are latency-bound and cutting them up only adds launches).
 	 * A single rank only cuts its products up when the collectives are forced on (tests). */
-	int K = 1;
+	q.K = 1;
 	if (nranks > 1 || c->force_comm) {
 		if (c->ag_chunks > 0) {
-			K = c->ag_chunks;
+			q.K = c->ag_chunks;
 		} else {
 			/* Cutting a product into K pieces leaves 1/K of it exposed after the last all-gather but pays K
 			 * collective start-ups (and 6-30 % more product time): exposed time
 			 * T/K + K*t0 is smallest at K = sqrt(T/t0), with T = this rank's product at the measured
 			 * ~55 G gathers/s and t0 ~ 25 us per all-gather call.  Pieces stay above ~2 MB per slab. */
-			const int64_t rows = std::min(right ? M->ncols : M->nrows, right ? M->nrows : M->ncols) / nranks;
+			const int64_t rows = std::min(mrows, mcols) / nranks;
 			const int64_t slab_bytes = rows * c->cfg.n * c->cfg.word;
-			const double t_prod_us = (double)M->nnz / nranks / 55e3, t0_us = 25.0;
+			const double t_prod_us = (double)nnz / nranks / 55e3, t0_us = 25.0;
 			const int64_t by_time = (int64_t)(std::sqrt(t_prod_us / t0_us) + 0.5);
-			K = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, by_time), slab_bytes / (2 << 20)));
+			q.K = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, by_time), slab_bytes / (2 << 20)));
 		}
 	}
-	c->bounds[0].assign((size_t)nranks + 1, 0);
-	c->bounds[1].assign((size_t)nranks + 1, 0);
-	int rc;
-	int64_t hot[2] = { 0, 0 };	/* densest rows / columns of M numbered first (single rank only) */
-	c->hot_share[0] = c->hot_share[1] = 0.0;
-	c->locality[0] = c->locality[1] = 1.0;
-	c->order_kind = 0;
+	const char *ao = getenv("BLZ_REORDER_PLAIN");	/* 1: round 1's order without the scored choice (A/B) */
+	q.reorder = !c->reorder ? 0 : ((ao && ao[0] == '1') ? 2 : 1);
+	q.rows_per_line = std::max(1, 128 / (c->cfg.n * c->cfg.word));
+	/* densest rows / columns in front when they hold enough of the entries (one rank, products in one piece: the SpMV
+	 * keeps that many block rows of its operand in LDS, k_spmv_panel) */
+	q.hot_cap = 0;
+	if (c->cfg.panel && nranks == 1 && q.K == 1) {
+		q.hot_cap = spmv_panel_capacity(c->cfg);
+		if (const char *e = getenv("BLZ_PANEL_ROWS"))
+			q.hot_cap = std::min<int64_t>(q.hot_cap, std::max<int64_t>(0, atoll(e)));
+	}
+	q.min_share = 0.25;	/* below that the dense block rows are served from L2 at no cost to the fabric: measured on the
+				 * structured workload, 17 % of the entries in the panel = no change in time */
+	if (const char *e = getenv("BLZ_PANEL_MIN_PCT"))
+		q.min_share = atof(e) / 100.0;
+	return q;
+}
+
+extern "C" int blz_prepare_for(const blz_ctx *c, const blz_coo *M, int right, int nranks, blz_prepared **out)
+{
+	if (!c || !M || !out || nranks < 1)
+		return blz_fail(BLZ_EINVAL, "blz_prepare_for: bad argument");
+	const PrepParams q = prep_params(c, M->nrows, M->ncols, M->nnz, nranks);
+	return blz_prepare(M, right, nranks, q.K, q.reorder, q.rows_per_line, q.hot_cap, q.min_share, out);
+}
+
+extern "C" uint64_t blz_prepare_key(const blz_ctx *c, uint64_t content_hash, int64_t mrows, int64_t mcols, int64_t nnz,
+				    int right, int nranks)
+{
+	if (!c)
+		return 0;
+	const PrepParams q = prep_params(c, mrows, mcols, nnz, nranks);
+	uint64_t h = content_hash ^ 0x9E3779B97F4A7C15ull;
+	const uint64_t parts[] = { c->prime, (uint64_t)c->cfg.n, (uint64_t)c->cfg.word, (uint64_t)(right != 0), (uint64_t)nranks,
+				   (uint64_t)q.K, (uint64_t)q.reorder, (uint64_t)q.rows_per_line, (uint64_t)q.hot_cap,
+				   (uint64_t)(q.min_share * 1e6), (uint64_t)mrows, (uint64_t)mcols, (uint64_t)nnz, 2 /* format */ };
+	for (uint64_t x : parts)
+		h = (h ^ x) * 0x100000001b3ull;
+	return h ? h : 1;
+}
+
+extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int rank)
+{
+	if (!c || !P)
+		return blz_fail(BLZ_EINVAL, "blz_set_matrix_prepared: NULL argument");
+	const int nranks = P->nranks, right = P->right, K = P->chunks;
+	if (rank < 0 || rank >= nranks)
+		return blz_fail(BLZ_EINVAL, "blz_set_matrix: rank %d of %d", rank, nranks);
+	if (nranks > 1 && (unsigned __int128)nranks * c->prime > ((unsigned __int128)1 << 64))
+		return blz_fail(BLZ_EINVAL, "nranks * p must not exceed 2**64 (u64 all-reduce of residues)");
+	if (K > 1 && nranks == 1 && !c->force_comm)
+		return blz_fail(BLZ_EINVAL, "blz_set_matrix_prepared: the matrix was prepared in %d pieces for a single rank", K);
+	HIPCHK(hipSetDevice(c->device));
+	if (c->iter_graph) {
+		hipGraphExecDestroy(c->iter_graph);
+		c->iter_graph = nullptr;
+	}
+	c->right = right;
+	c->rank = rank;
+	c->nranks = nranks;
+	/* side 0 = rows of v: rows of M for a left kernel, columns of M for a right kernel
+	 * (sequential/lanczos_modp.c:592-593). */
+	c->glob_rows[0] = right ? P->ncols : P->nrows;
+	c->glob_rows[1] = right ? P->nrows : P->ncols;
+	c->row_side[0] = right ? 1 : 0;		/* rows of M   */
+	c->row_side[1] = right ? 0 : 1;		/* rows of M^T */
+	const int rs = right ? 1 : 0, cs = 1 - rs;	/* side of M's rows / columns */
 	for (int sd = 0; sd < 2; sd++) {
 		c->perm[sd].clear();
 		c->inv[sd].clear();
+		c->bounds[sd].assign(P->bounds[sd], P->bounds[sd] + nranks + 1);
+		c->stride[sd] = P->stride[sd];
+		c->first[sd] = c->bounds[sd][rank];
+		c->count[sd] = c->bounds[sd][rank + 1] - c->bounds[sd][rank];
 	}
-	if (c->reorder && M->nnz > 0) {
-		/* renumber both index spaces for locality, then shard the renumbered matrix */
-		const int rs = right ? 1 : 0, cs = 1 - rs;	/* side of M's rows / columns */
-		c->perm[rs].resize((size_t)M->nrows);
-		c->perm[cs].resize((size_t)M->ncols);
-		/* The renumbering: densest rows / columns in front when they hold enough of the entries (one rank, products in
-		 * one piece: the SpMV keeps that many block rows of its operand in LDS, k_spmv_panel), and behind them the
-		 * order that makes windows of consecutive rows touch the fewest lines of the operand (blz_reorder_auto). */
-		if (c->cfg.panel && nranks == 1 && K == 1) {
-			int64_t cap = spmv_panel_capacity(c->cfg);
-			if (const char *e = getenv("BLZ_PANEL_ROWS"))
-				cap = std::min<int64_t>(cap, std::max<int64_t>(0, atoll(e)));
-			hot[0] = hot[1] = cap;
-		}
-		double min_share = 0.25;	/* below that the dense block rows are served from L2 at no cost to the fabric: measured
-						 * on the structured workload, 17 % of the entries in the panel = no change in time */
-		if (const char *e = getenv("BLZ_PANEL_MIN_PCT"))
-			min_share = atof(e) / 100.0;
-		const int rows_per_line = std::max(1, 128 / (c->cfg.n * c->cfg.word));
-		const char *ao = getenv("BLZ_REORDER_PLAIN");	/* 1: round 1's order without the scored choice (A/B) */
-		if (ao && ao[0] == '1')
-			rc = blz_reorder_hot(M, c->perm[rs].data(), c->perm[cs].data(), hot, min_share, c->hot_share);
-		else
-			rc = blz_reorder_auto(M, c->perm[rs].data(), c->perm[cs].data(), hot, min_share, c->hot_share, rows_per_line,
-					      c->locality, &c->order_kind);
-		if (rc != BLZ_OK)
-			return rc;
+	if (P->has_perm) {
+		c->perm[rs].assign(P->perm[0], P->perm[0] + P->nrows);
+		c->perm[cs].assign(P->perm[1], P->perm[1] + P->ncols);
 		for (int sd = 0; sd < 2; sd++) {
 			c->inv[sd].resize(c->perm[sd].size());
 			for (size_t r = 0; r < c->perm[sd].size(); r++)
 				c->inv[sd][(size_t)c->perm[sd][r]] = (int32_t)r;
 		}
-		std::vector<int32_t> ni((size_t)M->nnz), nj((size_t)M->nnz);
-		blz_coo_relabel(M, c->perm[rs].data(), c->perm[cs].data(), ni.data(), nj.data());
-		blz_coo R = *M;
-		R.i = ni.data();
-		R.j = nj.data();
-		rc = blz_shard_matrix(&R, right, rank, nranks, K, slabs, c->bounds[0].data(), c->bounds[1].data(), c->stride);
-	} else {
-		rc = blz_shard_matrix(M, right, rank, nranks, K, slabs, c->bounds[0].data(), c->bounds[1].data(), c->stride);
 	}
-	if (rc != BLZ_OK)
-		return rc;
-	for (int sd = 0; sd < 2; sd++) {
-		c->first[sd] = c->bounds[sd][rank];
-		c->count[sd] = c->bounds[sd][rank + 1] - c->bounds[sd][rank];
-	}
+	/* what the renumbering found, per product (t = 0: M * x gathers by column; t = 1: M^T * x gathers by row) */
+	c->hot_share[0] = P->share[0];
+	c->hot_share[1] = P->share[1];
+	c->locality[0] = P->locality[0];
+	c->locality[1] = P->locality[1];
+	c->order_kind = P->order_kind;
 	for (int t = 0; t < 2; t++) {
 		for (auto &A : c->csr[t])
 			free_csr(A);
 		c->csr[t].assign((size_t)K, DevCsr{});
 	}
+	int rc = BLZ_OK;
 	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
+		blz_csr slab;
+		memset(&slab, 0, sizeof slab);
+		const bool whole = nranks == 1;		/* one rank: the slab IS the prepared CSR, no copy */
+		if (whole)
+			slab = P->full[t];
+		else if ((rc = blz_prepared_slab(P, rank, t, &slab)) != BLZ_OK)
+			break;
 		if (K == 1) {
-			/* product t gathers block rows by the column index of slabs[t]: columns of M for t = 0, rows of M for t = 1 */
-			const int64_t hot_t = hot[t == 0 ? 1 : 0];
-			if (hot_t > 0)
-				blz_csr_sort_rows(&slabs[t]);
-			rc = upload_csr(c, slabs[t], c->csr[t][0], hot_t);
-			{
-				const char *xe = getenv("BLZ_XCD_RANGES");	/* 0 / 1 force it off / on (A/B) */
-				/* (an operand of a few MB sits in every L2 anyway: nothing to separate) */
-				const bool big = (double)slabs[t].cols * c->cfg.n * c->cfg.word > 8e6;
-				c->csr[t][0].xcd_ranges = xe ? xe[0] == '1' : (c->locality[t] < 0.6 && big);
-			}
+			/* product t gathers block rows by the column index of its slab: columns of M for t = 0, rows of M for t = 1 */
+			const int64_t hot_t = c->cfg.panel ? P->hot[t == 0 ? 1 : 0] : 0;
+			rc = upload_csr(c, slab, c->csr[t][0], hot_t);
+			const char *xe = getenv("BLZ_XCD_RANGES");	/* 0 / 1 force it off / on (A/B) */
+			/* (an operand of a few MB sits in every L2 anyway: nothing to separate) */
+			const bool big = (double)slab.cols * c->cfg.n * c->cfg.word > 8e6;
+			c->csr[t][0].xcd_ranges = xe ? xe[0] == '1' : (c->locality[t] < 0.6 && big);
 		} else {
 			/* columns are positions in the gathered operand of the opposite side: piece k = [k*w, (k+1)*w) */
-			const int cs = 1 - c->row_side[t];
-			const int64_t width = (c->stride[cs] / K) * nranks;
+			const int csd = 1 - c->row_side[t];
+			const int64_t width = (c->stride[csd] / K) * nranks;
 			std::vector<blz_csr> piece((size_t)K);
-			rc = blz_csr_split_columns(&slabs[t], width, K, piece.data());
+			rc = blz_csr_split_columns(&slab, width, K, piece.data());
 			for (int k = 0; k < K && rc == BLZ_OK; k++)
 				rc = upload_csr(c, piece[(size_t)k], c->csr[t][(size_t)k]);
 			for (auto &pc : piece)
 				blz_csr_free(&pc);
 		}
+		if (!whole)
+			blz_csr_free(&slab);
 	}
-	blz_csr_free(&slabs[0]);
-	blz_csr_free(&slabs[1]);
 	if (rc != BLZ_OK)
 		return rc;
 
@@ -585,6 +626,23 @@ extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank,
 	c->host_ctl = DevCtl{};
 	c->have_matrix = true;
 	return BLZ_OK;
+}
+
+/* The one-call form: prepare for this context, keep this rank's share, drop the rest.  Several contexts of one process
+ * (or several processes on a node) should prepare ONCE and call blz_set_matrix_prepared instead. */
+extern "C" int blz_set_matrix(blz_ctx *c, const blz_coo *M, int right, int rank, int nranks)
+{
+	if (!c || !M)
+		return blz_fail(BLZ_EINVAL, "blz_set_matrix: NULL argument");
+	if (nranks < 1 || rank < 0 || rank >= nranks)
+		return blz_fail(BLZ_EINVAL, "blz_set_matrix: rank %d of %d", rank, nranks);
+	blz_prepared *P = nullptr;
+	int rc = blz_prepare_for(c, M, right, nranks, &P);
+	if (rc != BLZ_OK)
+		return rc;
+	rc = blz_set_matrix_prepared(c, P, rank);
+	blz_prepared_free(P);
+	return rc;
 }
 
 extern "C" int64_t blz_rows(const blz_ctx *c, int block)
@@ -879,6 +937,9 @@ static inline bool exchanging(const blz_ctx *c)
 	return !c->external_exchange && (c->nranks > 1 || (c->force_comm && c->comm));
 }
 
+/* where k_dot_finalize puts this rank's sums: straight into `small` on one rank, into the send buffer otherwise */
+static inline u64 *dot_out(blz_ctx *c);
+
 static int allreduce_dots(blz_ctx *c)
 {
 	if (!exchanging(c))
@@ -887,11 +948,16 @@ static int allreduce_dots(blz_ctx *c)
 		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
 	Span sp(c, PK_AR);
 	/* residues < p and nranks * p <= 2^64 (checked in blz_set_matrix): the u64 sum cannot wrap; the
-	 * semi_inverse kernel reduces it mod p.  (mpi/lanczos_modp.c:1209-1247 does this by hand.) */
-	NCCLCHK(g_rccl.AllReduce(c->small, c->small, (size_t)2 * c->cfg.n * c->cfg.n, ncclUint64, ncclSum, c->comm,
+	 * semi_inverse kernel reduces it mod p.  (mpi/lanczos_modp.c:1209-1247 does this by hand.)
+	 * Out of place, from the rank's own partial sums (dot_out) into `small`: once the stop flag is up k_dot_finalize
+	 * leaves dot_send alone, so the iterations a batch enqueues past the stop reduce the same words again and `small`
+	 * keeps its value (in place, every such iteration multiplied it by the number of ranks). */
+	NCCLCHK(g_rccl.AllReduce(c->dot_send, c->small, (size_t)2 * c->cfg.n * c->cfg.n, ncclUint64, ncclSum, c->comm,
 				 c->stream));
 	return BLZ_OK;
 }
+
+static inline u64 *dot_out(blz_ctx *c) { return exchanging(c) ? c->dot_send : c->small; }
 
 /*
  * One product of the iteration: slab[dst] = (transpose ? M^T : M)[this rank's rows] * block `src`, with the
@@ -955,7 +1021,7 @@ static int enqueue_dot(blz_ctx *c)
 	Span sp(c, PK_DOT);
 	HIPCHK(launch_block_dot(c->cfg, slab_ptr(c, BLZ_V), slab_ptr(c, BLZ_AV), c->count[0], c->partial,
 				std::min(c->max_dot_blocks, c->cfg.num_cu * 8), &nb, c->ctl, c->stream));
-	HIPCHK(launch_dot_finalize(c->cfg, c->partial, nb, c->small, c->ctl, c->stream));
+	HIPCHK(launch_dot_finalize(c->cfg, c->partial, nb, dot_out(c), c->ctl, c->stream));
 	}
 	return allreduce_dots(c);
 }
@@ -1046,7 +1112,7 @@ static int enqueue_iteration(blz_ctx *c)
 		if ((rc = enqueue_product(c, c->right, BLZ_TMP, BLZ_AV, true, &nb)) != BLZ_OK) return rc;
 		{
 			Span sp(c, PK_DOT);
-			HIPCHK(launch_dot_finalize(c->cfg, c->partial, nb, c->small, c->ctl, c->stream));
+			HIPCHK(launch_dot_finalize(c->cfg, c->partial, nb, dot_out(c), c->ctl, c->stream));
 		}
 		if ((rc = allreduce_dots(c)) != BLZ_OK) return rc;
 	} else {
@@ -1197,6 +1263,78 @@ extern "C" int blz_profile_read(blz_ctx *c, double *ms_sum, int64_t *launches)
 		ms_sum[sp.cls] += ms;
 		launches[sp.cls] += 1;
 	}
+	return BLZ_OK;
+}
+
+/*
+ * Asynchronous snapshot of (v, p, iteration count) for checkpoints -- openMP/lanczos_modp.c:1013-1022 stops the loop,
+ * and round 1 did too (two synchronous blz_get_block calls and the file write on the loop thread).
+ * blz_snapshot_begin: between two blz_iterate calls; enqueues the device-to-host copies of this rank's rows of v and p
+ * into pinned staging on a stream of their own and makes the compute stream wait for them (the next iteration's update
+ * writes v and p in place), then returns: the host thread goes on enqueuing iterations, the GPU pauses for the PCIe
+ * transfer only (2 x 122 MB ~ 5 ms on the GL7d19 shape; config 5's 2 x 6.4 GB ~ 0.26 s per 60 s checkpoint interval).
+ * blz_snapshot_wait: blocks until the copies have landed and unpacks this rank's rows into v / p (original numbering,
+ * caller's width).  It touches only the snapshot's own staging and events, so it MAY be called from another host thread
+ * (the checkpoint writer) while the owning thread is inside blz_iterate -- the one exception to one-thread-per-handle.
+ */
+extern "C" int blz_snapshot_begin(blz_ctx *c)
+{
+	NEED_MATRIX(c);
+	if (c->snap_pending)
+		return blz_fail(BLZ_EINVAL, "blz_snapshot_begin: the previous snapshot has not been collected (blz_snapshot_wait)");
+	if (!c->cstream) {
+		HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+		HIPCHK(hipEventCreateWithFlags(&c->ev_snap_go, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&c->ev_snap_done, hipEventDisableTiming));
+	}
+	const size_t bytes = (size_t)std::max<int64_t>(c->count[0], 1) * c->cfg.n * c->cfg.word;
+	if (bytes > c->snap_bytes) {
+		for (void *&h : c->snap_host) {
+			if (h) hipHostFree(h);
+			h = nullptr;
+			HIPCHK(hipHostMalloc(&h, bytes, hipHostMallocDefault));
+		}
+		c->snap_bytes = bytes;
+	}
+	HIPCHK(hipEventRecord(c->ev_snap_go, c->stream));
+	HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_snap_go, 0));
+	HIPCHK(hipMemcpyAsync(c->snap_host[0], c->slab[BLZ_V], bytes, hipMemcpyDeviceToHost, c->cstream));
+	HIPCHK(hipMemcpyAsync(c->snap_host[1], c->slab[BLZ_P], bytes, hipMemcpyDeviceToHost, c->cstream));
+	HIPCHK(hipEventRecord(c->ev_snap_done, c->cstream));
+	HIPCHK(hipStreamWaitEvent(c->stream, c->ev_snap_done, 0));	/* later kernels overwrite v and p in place */
+	c->snap_iterations = c->host_ctl.iterations;
+	c->snap_pending = true;
+	return BLZ_OK;
+}
+
+extern "C" int blz_snapshot_wait(blz_ctx *c, uint64_t *v, uint64_t *p, int64_t *iterations)
+{
+	if (!c || !v || !p)
+		return blz_fail(BLZ_EINVAL, "blz_snapshot_wait: NULL argument");
+	if (!c->snap_pending)
+		return blz_fail(BLZ_EINVAL, "blz_snapshot_wait: no snapshot in flight");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipEventSynchronize(c->ev_snap_done));
+	const int un = c->un, np = c->cfg.n, sd = 0;
+	uint64_t *dst[2] = { v, p };
+	for (int b = 0; b < 2; b++) {
+		const char *src = (const char *)c->snap_host[b];
+		for (int64_t q = 0; q < c->count[sd]; q++) {
+			const int64_t solver_row = c->first[sd] + q;
+			const int64_t orig = c->inv[sd].empty() ? solver_row : c->inv[sd][(size_t)solver_row];
+			uint64_t *out = dst[b] + (size_t)orig * un;
+			if (c->cfg.word == 8) {
+				memcpy(out, src + (size_t)q * np * 8, (size_t)un * 8);
+			} else {
+				const u32 *row = (const u32 *)(src + (size_t)q * np * 4);
+				for (int l = 0; l < un; l++)
+					out[l] = row[l];
+			}
+		}
+	}
+	if (iterations)
+		*iterations = c->snap_iterations;
+	c->snap_pending = false;
 	return BLZ_OK;
 }
 

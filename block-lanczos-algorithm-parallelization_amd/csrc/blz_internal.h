@@ -24,6 +24,20 @@ void blz_coo_relabel(const blz_coo *M, const int32_t *row_perm, const int32_t *c
 /* Rows [r0, r1) of A as a standalone CSR (deep copy). */
 int blz_csr_slab(const blz_csr *A, int64_t r0, int64_t r1, blz_csr *out);
 
+/* the prepared matrix (include/blz.h: blz_prepare); arrays are malloc'ed, or live in the mmapped cache file when map != NULL */
+struct blz_prepared {
+	int64_t nrows, ncols, nnz;		/* of M */
+	int right, nranks, chunks, order_kind, has_perm;
+	int64_t hot[2];				/* densest rows / columns of M numbered first (0 = none) */
+	double share[2], locality[2];
+	int32_t *perm[2];			/* new index of every row / column of M (has_perm) */
+	int64_t *bounds[2];			/* per SIDE (0: rows of v, 1: rows of tmp): nranks + 1 row bounds */
+	int64_t stride[2];			/* per side: rows of a padded slab */
+	blz_csr full[2];			/* CSR of M and of M^T in the solver's numbering, global column indices */
+	void *map;
+	size_t map_len;
+};
+
 #ifdef __cplusplus
 }
 #endif

@@ -1145,6 +1145,307 @@ int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, int chun
 	return rc;
 }
 
+/* ----------------------------------------------------- the prepared matrix: set-up done once, shared, cacheable */
+
+/*
+ * Everything blz_set_matrix needs that does NOT depend on the rank: the renumbering, CSR(M) and CSR(M^T) in the
+ * solver's numbering, the nnz-balanced row partition of both sides.  Round 1 redid all of it in every rank (and kept
+ * 1/N of the result); now it is made once -- by the CLI's main thread for its G contexts, by rank 0 of a
+ * multi-process job -- and each rank cuts its slab out of it (blz_prepared_slab).  Saved to a file it is the binary
+ * cache SURVEY 8(f)1 asks for: the text parser is fast (0.5 s for 724 MB), what a second run saves is the renumbering
+ * and the two CSR builds (GL7d19 shape ~1 s, config 5 ~48 s per rank).  A loaded cache is mmapped: N processes on one
+ * node share its pages.
+ */
+#define PREP_MAGIC "BLZPREP2"
+
+typedef struct {
+	char magic[8];
+	uint64_t key;
+	int64_t nrows, ncols, nnz;
+	int32_t right, nranks, chunks, order_kind, has_perm, has_val[2];
+	int64_t hot[2], stride[2];
+	double share[2], locality[2];
+	uint64_t off_perm[2], off_bounds[2], off_rp[2], off_ci[2], off_va[2];
+	uint64_t total;
+} prep_header;
+
+void blz_prepared_free(blz_prepared *P)
+{
+	if (!P)
+		return;
+	if (P->map) {
+		munmap(P->map, P->map_len);
+	} else {
+		for (int q = 0; q < 2; q++) {
+			free(P->perm[q]);
+			free(P->bounds[q]);
+			blz_csr_free(&P->full[q]);
+		}
+	}
+	free(P);
+}
+
+int blz_prepare(const blz_coo *M, int right, int nranks, int chunks, int reorder, int rows_per_line, int64_t hot_cap,
+		double min_share, blz_prepared **out)
+{
+	if (!M || !out || nranks < 1 || chunks < 1 || rows_per_line < 1)
+		return blz_fail(BLZ_EINVAL, "blz_prepare: bad argument");
+	*out = NULL;
+	blz_prepared *P = calloc(1, sizeof *P);
+	if (!P)
+		return blz_fail(BLZ_ENOMEM, "blz_prepare: out of memory");
+	P->nrows = M->nrows;
+	P->ncols = M->ncols;
+	P->nnz = M->nnz;
+	P->right = right ? 1 : 0;
+	P->nranks = nranks;
+	P->chunks = chunks;
+	P->locality[0] = P->locality[1] = 1.0;
+	int rc = BLZ_OK;
+	blz_coo R = *M;
+	int32_t *ni = NULL, *nj = NULL;
+	if (reorder && M->nnz > 0) {
+		P->perm[0] = malloc(sizeof(int32_t) * (size_t)(M->nrows ? M->nrows : 1));
+		P->perm[1] = malloc(sizeof(int32_t) * (size_t)(M->ncols ? M->ncols : 1));
+		ni = malloc(sizeof *ni * (size_t)M->nnz);
+		nj = malloc(sizeof *nj * (size_t)M->nnz);
+		if (!P->perm[0] || !P->perm[1] || !ni || !nj)
+			rc = blz_fail(BLZ_ENOMEM, "blz_prepare: out of memory");
+		if (rc == BLZ_OK) {
+			P->hot[0] = P->hot[1] = (nranks == 1 && chunks == 1) ? hot_cap : 0;
+			if (reorder == 2)	/* round 1's order, no scored choice (A/B) */
+				rc = blz_reorder_hot(M, P->perm[0], P->perm[1], P->hot, min_share, P->share);
+			else
+				rc = blz_reorder_auto(M, P->perm[0], P->perm[1], P->hot, min_share, P->share, rows_per_line,
+						      P->locality, &P->order_kind);
+		}
+		if (rc == BLZ_OK) {
+			P->has_perm = 1;
+			blz_coo_relabel(M, P->perm[0], P->perm[1], ni, nj);
+			R.i = ni;
+			R.j = nj;
+		}
+	}
+	for (int t = 0; t < 2 && rc == BLZ_OK; t++)
+		rc = blz_csr_from_coo(&R, t, 1, &P->full[t]);
+	free(ni);
+	free(nj);
+	/* rows of M live on side 0 for a left kernel and on side 1 for a right kernel; M^T the other way */
+	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
+		const int sd = t == 0 ? (right ? 1 : 0) : (right ? 0 : 1);
+		P->bounds[sd] = malloc(sizeof(int64_t) * (size_t)(nranks + 1));
+		if (!P->bounds[sd]) {
+			rc = blz_fail(BLZ_ENOMEM, "blz_prepare: out of memory");
+			break;
+		}
+		blz_partition_rows(&P->full[t], nranks, P->bounds[sd]);
+		int64_t mx = 0;
+		for (int g = 0; g < nranks; g++)
+			if (P->bounds[sd][g + 1] - P->bounds[sd][g] > mx)
+				mx = P->bounds[sd][g + 1] - P->bounds[sd][g];
+		P->stride[sd] = (mx + chunks - 1) / chunks * chunks;	/* slab rows, padded to a whole number of pieces */
+		/* product t gathers by the column index of full[t]: columns of M for t = 0 (hot[1]), rows of M for t = 1 */
+		if (P->hot[t == 0 ? 1 : 0] > 0)
+			blz_csr_sort_rows(&P->full[t]);
+	}
+	if (rc != BLZ_OK) {
+		blz_prepared_free(P);
+		return rc;
+	}
+	*out = P;
+	return BLZ_OK;
+}
+
+/* rank `rank`'s rows of M (t = 0) or M^T (t = 1), columns rewritten to positions in the gathered operand */
+int blz_prepared_slab(const blz_prepared *P, int rank, int t, blz_csr *slab)
+{
+	if (!P || !slab || rank < 0 || rank >= P->nranks || t < 0 || t > 1)
+		return blz_fail(BLZ_EINVAL, "blz_prepared_slab: bad argument");
+	const int rs = t == 0 ? (P->right ? 1 : 0) : (P->right ? 0 : 1), cs = 1 - rs;
+	int rc = blz_csr_slab(&P->full[t], P->bounds[rs][rank], P->bounds[rs][rank + 1], slab);
+	if (rc == BLZ_OK && P->nranks > 1) {
+		blz_remap_columns(slab, P->bounds[cs], P->nranks, P->stride[cs] / P->chunks, P->chunks);
+		slab->cols = P->stride[cs] * P->nranks;
+	}
+	return rc;
+}
+
+static uint64_t up64(uint64_t x) { return (x + 63u) & ~(uint64_t)63u; }
+
+int blz_prepared_save(const blz_prepared *P, const char *path, uint64_t key)
+{
+	if (!P || !path)
+		return blz_fail(BLZ_EINVAL, "blz_prepared_save: bad argument");
+	prep_header h;
+	memset(&h, 0, sizeof h);
+	memcpy(h.magic, PREP_MAGIC, 8);
+	h.key = key;
+	h.nrows = P->nrows;
+	h.ncols = P->ncols;
+	h.nnz = P->nnz;
+	h.right = P->right;
+	h.nranks = P->nranks;
+	h.chunks = P->chunks;
+	h.order_kind = P->order_kind;
+	h.has_perm = P->has_perm;
+	uint64_t at = up64(sizeof h);
+	const int64_t plen[2] = { P->nrows, P->ncols };
+	for (int q = 0; q < 2; q++) {
+		h.hot[q] = P->hot[q];
+		h.stride[q] = P->stride[q];
+		h.share[q] = P->share[q];
+		h.locality[q] = P->locality[q];
+		h.has_val[q] = P->full[q].val != NULL;
+		if (P->has_perm) {
+			h.off_perm[q] = at;
+			at = up64(at + sizeof(int32_t) * (uint64_t)plen[q]);
+		}
+		h.off_bounds[q] = at;
+		at = up64(at + sizeof(int64_t) * (uint64_t)(P->nranks + 1));
+		h.off_rp[q] = at;
+		at = up64(at + sizeof(uint32_t) * (uint64_t)(P->full[q].rows + 1));
+		h.off_ci[q] = at;
+		at = up64(at + sizeof(int32_t) * (uint64_t)P->full[q].nnz);
+		if (h.has_val[q]) {
+			h.off_va[q] = at;
+			at = up64(at + sizeof(uint32_t) * (uint64_t)P->full[q].nnz);
+		}
+	}
+	h.total = at;
+	char tmp[4096];
+	snprintf(tmp, sizeof tmp, "%s.tmp.%d", path, (int)getpid());
+	const int fd = open(tmp, O_RDWR | O_CREAT | O_TRUNC, 0644);
+	if (fd < 0)
+		return blz_fail(BLZ_EIO, "cannot open %s: %s", tmp, strerror(errno));
+	if (ftruncate(fd, (off_t)h.total) != 0) {
+		close(fd);
+		unlink(tmp);
+		return blz_fail(BLZ_EIO, "cannot size %s: %s", tmp, strerror(errno));
+	}
+	char *m = mmap(NULL, h.total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+	close(fd);
+	if (m == MAP_FAILED) {
+		unlink(tmp);
+		return blz_fail(BLZ_EIO, "cannot map %s: %s", tmp, strerror(errno));
+	}
+	memcpy(m, &h, sizeof h);
+	for (int q = 0; q < 2; q++) {
+		if (P->has_perm)
+			memcpy(m + h.off_perm[q], P->perm[q], sizeof(int32_t) * (size_t)plen[q]);
+		memcpy(m + h.off_bounds[q], P->bounds[q], sizeof(int64_t) * (size_t)(P->nranks + 1));
+		memcpy(m + h.off_rp[q], P->full[q].row_ptr, sizeof(uint32_t) * (size_t)(P->full[q].rows + 1));
+		memcpy(m + h.off_ci[q], P->full[q].col_idx, sizeof(int32_t) * (size_t)P->full[q].nnz);
+		if (h.has_val[q])
+			memcpy(m + h.off_va[q], P->full[q].val, sizeof(uint32_t) * (size_t)P->full[q].nnz);
+	}
+	const int bad = msync(m, h.total, MS_SYNC) != 0;
+	munmap(m, h.total);
+	if (bad || rename(tmp, path) != 0) {	/* atomic: a reader sees the old cache or the whole new one */
+		unlink(tmp);
+		return blz_fail(BLZ_EIO, "cannot write %s: %s", path, strerror(errno));
+	}
+	return BLZ_OK;
+}
+
+int blz_prepared_load(const char *path, uint64_t key, blz_prepared **out)
+{
+	if (!path || !out)
+		return blz_fail(BLZ_EINVAL, "blz_prepared_load: bad argument");
+	*out = NULL;
+	const int fd = open(path, O_RDONLY);
+	if (fd < 0)
+		return blz_fail(BLZ_EIO, "cannot open %s: %s", path, strerror(errno));
+	struct stat st;
+	if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(prep_header)) {
+		close(fd);
+		return blz_fail(BLZ_EFORMAT, "%s is not a prepared-matrix cache", path);
+	}
+	char *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+	close(fd);
+	if (m == MAP_FAILED)
+		return blz_fail(BLZ_EIO, "cannot map %s: %s", path, strerror(errno));
+	prep_header h;
+	memcpy(&h, m, sizeof h);
+	if (memcmp(h.magic, PREP_MAGIC, 8) != 0 || h.total != (uint64_t)st.st_size || h.key != key || h.nranks < 1) {
+		munmap(m, (size_t)st.st_size);
+		return blz_fail(BLZ_EFORMAT, "%s: not a cache of this matrix / prime / width / rank count (or an older format)", path);
+	}
+	blz_prepared *P = calloc(1, sizeof *P);
+	if (!P) {
+		munmap(m, (size_t)st.st_size);
+		return blz_fail(BLZ_ENOMEM, "blz_prepared_load: out of memory");
+	}
+	P->map = m;
+	P->map_len = (size_t)st.st_size;
+	P->nrows = h.nrows;
+	P->ncols = h.ncols;
+	P->nnz = h.nnz;
+	P->right = h.right;
+	P->nranks = h.nranks;
+	P->chunks = h.chunks;
+	P->order_kind = h.order_kind;
+	P->has_perm = h.has_perm;
+	for (int q = 0; q < 2; q++) {
+		P->hot[q] = h.hot[q];
+		P->stride[q] = h.stride[q];
+		P->share[q] = h.share[q];
+		P->locality[q] = h.locality[q];
+		P->perm[q] = h.has_perm ? (int32_t *)(m + h.off_perm[q]) : NULL;
+		P->bounds[q] = (int64_t *)(m + h.off_bounds[q]);
+		P->full[q].rows = q == 0 ? h.nrows : h.ncols;
+		P->full[q].cols = q == 0 ? h.ncols : h.nrows;
+		P->full[q].nnz = h.nnz;
+		P->full[q].row_ptr = (uint32_t *)(m + h.off_rp[q]);
+		P->full[q].col_idx = (int32_t *)(m + h.off_ci[q]);
+		P->full[q].val = h.has_val[q] ? (uint32_t *)(m + h.off_va[q]) : NULL;
+	}
+	*out = P;
+	return BLZ_OK;
+}
+
+/* 64-bit content hash of a file (FNV-1a over 8-byte words, 1 MB pieces hashed in parallel and chained): the cache key
+ * of the CLI.  0 on error. */
+uint64_t blz_file_hash(const char *path)
+{
+	const int fd = open(path, O_RDONLY);
+	if (fd < 0)
+		return 0;
+	struct stat st;
+	if (fstat(fd, &st) != 0 || st.st_size <= 0) {
+		close(fd);
+		return 0;
+	}
+	const size_t len = (size_t)st.st_size;
+	const unsigned char *m = mmap(NULL, len, PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (m == MAP_FAILED)
+		return 0;
+	const size_t piece = 1u << 20, np = (len + piece - 1) / piece;
+	uint64_t *hp = malloc(sizeof *hp * np);
+	uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)len;
+	if (hp) {
+#pragma omp parallel for schedule(static)
+		for (int64_t q = 0; q < (int64_t)np; q++) {
+			const size_t lo = (size_t)q * piece, hi = lo + piece < len ? lo + piece : len;
+			uint64_t x = 0xcbf29ce484222325ull;
+			size_t k = lo;
+			for (; k + 8 <= hi; k += 8) {
+				uint64_t wd;
+				memcpy(&wd, m + k, 8);
+				x = (x ^ wd) * 0x100000001b3ull;
+			}
+			for (; k < hi; k++)
+				x = (x ^ m[k]) * 0x100000001b3ull;
+			hp[q] = x;
+		}
+		for (size_t q = 0; q < np; q++)
+			h = (h ^ hp[q]) * 0x100000001b3ull;
+		free(hp);
+	}
+	munmap((void *)m, len);
+	return h ? h : 1;
+}
+
 /* --------------------------------------------------------------------------------- RNG */
 
 /* sequential/lanczos_modp.c:67 */

@@ -6,7 +6,8 @@
  * sequential/lanczos_modp.c (main :690-705, options :141-194) plus the checkpoint flags of
  * openMP/lanczos_modp.c:189-243.  Differences, all stated in --help:
  *   - the prime may be anything in [2, 2^62) (the reference stops at 2^30-35, :189-193);
- *   - checkpoints are one binary file written atomically (lanczos_modp.ckpt in the CWD);
+ *   - checkpoints are one binary file written atomically (lanczos_modp.ckpt in the CWD) by a helper thread from an
+ *     asynchronous snapshot: the main loop does not stop for them (openMP/lanczos_modp.c:1013-1022 does);
  *     with BLZ_REF_CHECKPOINT=1 and p < 2^32 the reference's five text files are written too, and
  *     --load-checkpoint falls back to them when the binary file is absent.
  */
@@ -28,7 +29,7 @@
 static long n = 1;
 static uint64_t prime;
 static char *matrix_filename, *kernel_filename;
-static bool right_kernel, checkpoints, load_checkpoint, verify;
+static bool right_kernel, checkpoints, load_checkpoint, verify, use_cache;
 static int stop_after = -1, checkpoint_timer = 60, device, gpus = 1;
 
 static double wtime(void)
@@ -68,6 +69,9 @@ static void usage(char **argv)
 	printf("--load-checkpoint           restart from the checkpoint in the current directory\n");
 	printf("--verify                    check the reference's per-iteration invariants (correctness_tests) on the host;\n");
 	printf("                            one host round trip per iteration, for debugging\n");
+	printf("--cache                     keep the renumbered CSR(M), CSR(M^T) and the row partition next to the matrix\n");
+	printf("                            (FILENAME.<key>.blzcache, keyed by content hash, prime, n, orientation, GPUs);\n");
+	printf("                            a later run with the same arguments skips the renumbering and the CSR builds\n");
 	printf("--device D                  first HIP device to run on [default 0]\n");
 	printf("--gpus G                    row-partition the matrix over G GPUs of this node (devices D..D+G-1), RCCL\n");
 	printf("                            all-gather of the block before each product [default 1]\n");
@@ -86,7 +90,7 @@ static void process_command_line_options(int argc, char **argv)
 		{"stop-after", required_argument, NULL, 's'}, {"checkpoint", optional_argument, NULL, 'c'},
 		{"load-checkpoint", no_argument, NULL, 'L'}, {"device", required_argument, NULL, 'd'},
 		{"gpus", required_argument, NULL, 'g'}, {"verify", no_argument, NULL, 'V'},
-		{"help", no_argument, NULL, 'h'}, {NULL, 0, NULL, 0}
+		{"cache", no_argument, NULL, 'C'}, {"help", no_argument, NULL, 'h'}, {NULL, 0, NULL, 0}
 	};
 	int ch;
 	while ((ch = getopt_long(argc, argv, "", longopts, NULL)) != -1) {
@@ -109,6 +113,7 @@ static void process_command_line_options(int argc, char **argv)
 		case 'd': device = atoi(optarg); break;
 		case 'g': gpus = atoi(optarg); break;
 		case 'V': verify = true; break;
+		case 'C': use_cache = true; break;
 		case 'h': usage(argv); break;
 		default: errx(1, "Unknown option\n");
 		}
@@ -201,11 +206,11 @@ static void correctness_tests(blz_ctx *ctx)
  * blz_comm_init / blz_iterate / blz_final_check must be entered by all ranks concurrently).  With --gpus 1 the
  * operation runs on the calling thread.
  */
-enum { OP_SETUP, OP_INIT, OP_SET_VP, OP_ITERATE, OP_GET, OP_FINAL, OP_DESTROY };
+enum { OP_CREATE, OP_COMM, OP_MATRIX, OP_INIT, OP_SET_VP, OP_ITERATE, OP_GET, OP_FINAL, OP_SNAP, OP_DESTROY };
 
 static struct {
 	blz_ctx *ctx[64];
-	const blz_coo *M;
+	const blz_prepared *P;
 	char uid[128];
 	int op, todo, block;
 	uint64_t *host, *host2;
@@ -220,12 +225,16 @@ static void *team_worker(void *arg)
 	const int g = (int)(intptr_t)arg;
 	int rc = BLZ_OK;
 	switch (team.op) {
-	case OP_SETUP:
+	/* set-up in three phases with a join after each: a rank that fails in one of them (no memory on its device, say) is
+	 * reported before its peers enter the next, instead of leaving them inside ncclCommInitRank for ever */
+	case OP_CREATE:
 		rc = blz_create(&team.ctx[g], device + g, prime, (int)n);
-		if (rc == BLZ_OK && gpus > 1)
-			rc = blz_comm_init(team.ctx[g], team.uid, sizeof team.uid, g, gpus);
-		if (rc == BLZ_OK)
-			rc = blz_set_matrix(team.ctx[g], team.M, right_kernel, g, gpus);
+		break;
+	case OP_COMM:
+		rc = blz_comm_init(team.ctx[g], team.uid, sizeof team.uid, g, gpus);
+		break;
+	case OP_MATRIX:
+		rc = blz_set_matrix_prepared(team.ctx[g], team.P, g);
 		break;
 	case OP_INIT:
 		rc = blz_init_v(team.ctx[g]);
@@ -246,6 +255,9 @@ static void *team_worker(void *arg)
 	case OP_FINAL:
 		rc = blz_final_check(team.ctx[g], &team.nonzero[g], &team.zero[g]);
 		break;
+	case OP_SNAP:
+		rc = blz_snapshot_begin(team.ctx[g]);
+		break;
 	case OP_DESTROY:
 		blz_destroy(team.ctx[g]);
 		break;
@@ -263,11 +275,28 @@ static void team_run(int op)
 		team_worker((void *)(intptr_t)0);
 	} else {
 		pthread_t th[64];
-		for (int g = 0; g < gpus; g++)
+		for (int g = 0; g < gpus; g++) {
+			team.rc[g] = BLZ_OK;
 			if (pthread_create(&th[g], NULL, team_worker, (void *)(intptr_t)g))
 				errx(1, "cannot start a host thread for GPU %d", g);
-		for (int g = 0; g < gpus; g++)
-			pthread_join(th[g], NULL);
+		}
+		/* the communicator's rendez-vous is the one step where a missing rank leaves the others waiting inside RCCL:
+		 * give it a deadline and leave from the main thread instead of joining for ever */
+		struct timespec dl;
+		clock_gettime(CLOCK_REALTIME, &dl);
+		dl.tv_sec += 300;
+		for (int g = 0; g < gpus; g++) {
+			if (op == OP_COMM) {
+				if (pthread_timedjoin_np(th[g], NULL, &dl) != 0) {
+					for (int q = 0; q < gpus; q++)
+						if (team.rc[q] != BLZ_OK)
+							errx(1, "GPU %d: %s", device + q, team.err[q]);
+					errx(1, "GPU %d did not join the RCCL communicator within 300 s", device + g);
+				}
+			} else {
+				pthread_join(th[g], NULL);
+			}
+		}
 	}
 	for (int g = 0; g < gpus; g++)
 		if (team.rc[g] != BLZ_OK)
@@ -279,6 +308,39 @@ static void team_get(int block, uint64_t *host)
 	team.block = block;
 	team.host = host;
 	team_run(OP_GET);
+}
+
+/* the checkpoint writer: collects the snapshot every context has begun (blz_snapshot_wait is the one call that may come
+ * from another thread than the context's owner), writes lanczos_modp.ckpt atomically */
+static struct {
+	pthread_t th;
+	volatile bool busy;
+	bool started;
+	int64_t nrows;
+	uint64_t *v, *p;
+} writer;
+
+static void *checkpoint_writer(void *arg)
+{
+	(void)arg;
+	const size_t words = (size_t)(writer.nrows * n + 1);
+	if (!writer.v) {
+		writer.v = malloc(sizeof(uint64_t) * words);
+		writer.p = malloc(sizeof(uint64_t) * words);
+	}
+	int64_t its = 0;
+	int rc = (writer.v && writer.p) ? BLZ_OK : BLZ_ENOMEM;
+	for (int g = 0; g < gpus && rc == BLZ_OK; g++)
+		rc = blz_snapshot_wait(team.ctx[g], writer.v, writer.p, &its);
+	if (rc == BLZ_OK)
+		rc = blz_checkpoint_save("lanczos_modp.ckpt", prime, (int)n, right_kernel, writer.nrows, its, writer.v, writer.p);
+	if (rc == BLZ_OK)
+		printf("\n		>> Snapshot written to lanczos_modp.ckpt (iteration %" PRId64 ")\n", its);
+	else
+		fprintf(stderr, "\ncheckpoint NOT written: %s\n", rc == BLZ_ENOMEM ? "out of memory" : blz_last_error());
+	fflush(stdout);
+	writer.busy = false;
+	return NULL;
 }
 
 int main(int argc, char **argv)
@@ -297,11 +359,38 @@ int main(int argc, char **argv)
 
 	if (device < 0 || device + gpus > blz_device_count())
 		errx(1, "GPU %d..%d requested but %d HIP device(s) are visible", device, device + gpus - 1, blz_device_count());
-	if (gpus > 1)
+	team_run(OP_CREATE);
+	if (gpus > 1) {
 		CHECK(blz_comm_unique_id(team.uid, sizeof team.uid));
-	team.M = &M;
-	team_run(OP_SETUP);
+		team_run(OP_COMM);
+	}
 	blz_ctx *ctx = team.ctx[0];
+	/* the rank-independent set-up (renumbering, CSR(M), CSR(M^T), row partition) is done ONCE here -- round 1 redid it in
+	 * every context's thread -- or mapped from the cache of an earlier run (--cache) */
+	blz_prepared *P = NULL;
+	char cache_path[4096];
+	uint64_t key = 0;
+	const double t_prep = wtime();
+	if (use_cache) {
+		const uint64_t fh = blz_file_hash(matrix_filename);
+		key = blz_prepare_key(ctx, fh, M.nrows, M.ncols, M.nnz, right_kernel, gpus);
+		snprintf(cache_path, sizeof cache_path, "%s.%016" PRIx64 ".blzcache", matrix_filename, key);
+		if (fh && blz_prepared_load(cache_path, key, &P) == BLZ_OK)
+			fprintf(stderr, "  - Set-up mapped from %s in %.2fs\n", cache_path, wtime() - t_prep);
+	}
+	if (!P) {
+		CHECK(blz_prepare_for(ctx, &M, right_kernel, gpus, &P));
+		fprintf(stderr, "  - Renumbering, CSR(M), CSR(M^T), partition: %.2fs\n", wtime() - t_prep);
+		if (use_cache) {
+			if (blz_prepared_save(P, cache_path, key) == BLZ_OK)
+				fprintf(stderr, "  - Set-up saved to %s\n", cache_path);
+			else
+				fprintf(stderr, "  - (cache not written: %s)\n", blz_last_error());
+		}
+	}
+	team.P = P;
+	team_run(OP_MATRIX);
+	blz_prepared_free(P);
 	const int64_t nrows = right_kernel ? M.ncols : M.nrows;
 	const int64_t ncols = right_kernel ? M.nrows : M.ncols;
 	blz_coo_free(&M);
@@ -362,22 +451,42 @@ int main(int argc, char **argv)
 		if (ms < 250.0f && batch < 4096)
 			batch *= 2;
 		if (checkpoints && !stopped && (wtime() - checkpoint_start) >= checkpoint_timer) {
-			printf("\n");
-			team_get(BLZ_V, v);
-			team_get(BLZ_P, p);
-			printf("		>> Making a snapshot in lanczos_modp.ckpt (iteration %d)\n", n_iterations);
-			CHECK(blz_checkpoint_save("lanczos_modp.ckpt", prime, (int)n, right_kernel, nrows, n_iterations, v, p));
 			const char *ref = getenv("BLZ_REF_CHECKPOINT");
 			if (ref && ref[0] == '1' && prime < (1ull << 32)) {
+				/* the reference's five text files need tmp and Av too: the synchronous way, as round 1 did */
+				printf("\n");
+				team_get(BLZ_V, v);
+				team_get(BLZ_P, p);
+				printf("		>> Making a snapshot in lanczos_modp.ckpt (iteration %d)\n", n_iterations);
+				CHECK(blz_checkpoint_save("lanczos_modp.ckpt", prime, (int)n, right_kernel, nrows, n_iterations, v, p));
 				uint64_t *t = calloc((size_t)(ncols * n + 1), sizeof *t), *a = calloc((size_t)(nrows * n + 1), sizeof *a);
 				team_get(BLZ_TMP, t);
 				team_get(BLZ_AV, a);
 				CHECK(blz_checkpoint_save_ref_text(".", (int)n, nrows, ncols, n_iterations, start, wtime(), v, t, a, p));
 				free(t);
 				free(a);
+				checkpoint_start = wtime();
+			} else if (!writer.busy) {
+				/* asynchronous: the copies of v and p are enqueued on a side stream (the GPU pauses for the PCIe
+				 * transfer only), a helper thread waits for them, writes the file and renames it; the loop goes on.
+				 * A checkpoint that comes due while the previous one is still being written is skipped. */
+				if (writer.started) {
+					pthread_join(writer.th, NULL);
+					writer.started = false;
+				}
+				team_run(OP_SNAP);
+				writer.nrows = nrows;
+				writer.busy = true;
+				writer.started = true;
+				if (pthread_create(&writer.th, NULL, checkpoint_writer, NULL))
+					errx(1, "cannot start the checkpoint writer");
+				checkpoint_start = wtime();
 			}
-			checkpoint_start = wtime();
 		}
+	}
+	if (writer.started) {
+		pthread_join(writer.th, NULL);
+		writer.started = false;
 	}
 	printf("\n");
 

@@ -55,6 +55,10 @@ def lib():
         L.blz_local_nnz.restype = C.c_int64
         L.blz_matrix_stream_bytes.restype = C.c_int64
         L.blz_panel_rows.restype = C.c_int64
+        L.blz_prepare_key.restype = C.c_uint64
+        L.blz_file_hash.restype = C.c_uint64
+        L.blz_prepared_free.restype = None
+        L.blz_prepared_free.argtypes = [C.c_void_p]
         L.blz_destroy.restype = None
         L.blz_coo_free.restype = None
         L.blz_csr_free.restype = None
@@ -162,6 +166,66 @@ def shard_matrix(M, right, rank, nranks, chunks=1):
     return dict(slabs=out, bounds=[list(b0), list(b1)], stride=list(stride), chunks=chunks if nranks > 1 else 1)
 
 
+class Prepared:
+    """blz_prepared: the rank-independent part of a matrix's set-up (renumbering, CSR(M), CSR(M^T), partition), made once
+    (prepare / prepare_for), shared by several contexts, saved to and mmapped from a cache file."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @staticmethod
+    def prepare(M, right, nranks, chunks=1, reorder=1, rows_per_line=2, hot_cap=0, min_share=0.25):
+        h = C.c_void_p()
+        check(lib().blz_prepare(C.byref(M.c), C.c_int(int(right)), C.c_int(nranks), C.c_int(chunks), C.c_int(reorder),
+                                C.c_int(rows_per_line), C.c_int64(hot_cap), C.c_double(min_share), C.byref(h)))
+        return Prepared(h)
+
+    @staticmethod
+    def prepare_for(ctx, M, right, nranks):
+        h = C.c_void_p()
+        check(lib().blz_prepare_for(ctx.h, C.byref(M.c), C.c_int(int(right)), C.c_int(nranks), C.byref(h)))
+        return Prepared(h)
+
+    @staticmethod
+    def load(path, key):
+        h = C.c_void_p()
+        check(lib().blz_prepared_load(path.encode(), C.c_uint64(key), C.byref(h)))
+        return Prepared(h)
+
+    def save(self, path, key):
+        check(lib().blz_prepared_save(self.h, path.encode(), C.c_uint64(key)))
+
+    def slab(self, rank, t):
+        A = Csr()
+        check(lib().blz_prepared_slab(self.h, C.c_int(rank), C.c_int(t), C.byref(A)))
+        rp = np.ctypeslib.as_array(A.row_ptr, (A.rows + 1,)).copy()
+        ci = np.ctypeslib.as_array(A.col_idx, (max(A.nnz, 1),))[:A.nnz].copy()
+        va = np.ctypeslib.as_array(A.val, (max(A.nnz, 1),))[:A.nnz].copy() if A.val else np.ones(A.nnz, np.uint32)
+        out = dict(rows=int(A.rows), cols=int(A.cols), nnz=int(A.nnz), row_ptr=rp, col_idx=ci, val=va)
+        lib().blz_csr_free(C.byref(A))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().blz_prepared_free(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def prepare_key(ctx, content_hash, M, right, nranks):
+    return int(lib().blz_prepare_key(ctx.h, C.c_uint64(content_hash), C.c_int64(M.nrows), C.c_int64(M.ncols), C.c_int64(M.nnz),
+                                     C.c_int(int(right)), C.c_int(nranks)))
+
+
+def file_hash(path):
+    return int(lib().blz_file_hash(path.encode()))
+
+
 def reorder_hot(M, hot_rows, hot_cols, min_share=0.10):
     """blz_reorder_hot(): (row_perm, col_perm, (rows taken, columns taken), (their shares of the entries))."""
     rp = np.empty(M.nrows, dtype=np.int32)
@@ -266,6 +330,9 @@ class Context:
     def set_matrix(self, M, right=False, rank=0, nranks=1):
         check(lib().blz_set_matrix(self.h, C.byref(M.c), C.c_int(int(right)), C.c_int(rank), C.c_int(nranks)))
         self.right = bool(right)
+
+    def set_matrix_prepared(self, P, rank=0):
+        check(lib().blz_set_matrix_prepared(self.h, P.h, C.c_int(rank)))
 
     def rows(self, block):
         return int(lib().blz_rows(self.h, C.c_int(block)))
@@ -373,6 +440,20 @@ class Context:
 
     def set_exchange_mode(self, external):
         check(lib().blz_set_exchange_mode(self.h, C.c_int(int(external))))
+
+    def snapshot_begin(self):
+        check(lib().blz_snapshot_begin(self.h))
+
+    def snapshot_wait(self, v=None, p=None):
+        """(v, p, iterations) of the snapshot; this rank's rows are written into v / p (allocated zero if not given)."""
+        n = self.n
+        if v is None:
+            v = np.zeros(self.rows(V) * n, dtype=np.uint64)
+        if p is None:
+            p = np.zeros(self.rows(V) * n, dtype=np.uint64)
+        its = C.c_int64(0)
+        check(lib().blz_snapshot_wait(self.h, ptr(v), ptr(p), C.byref(its)))
+        return v, p, int(its.value)
 
     def sync(self):
         check(lib().blz_sync(self.h))

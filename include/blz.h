@@ -127,6 +127,29 @@ int blz_reorder_auto(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int
 /* entries of every row in ascending column order */
 void blz_csr_sort_rows(blz_csr *A);
 
+/* ---- the prepared matrix: everything blz_set_matrix needs that does not depend on the rank, made ONCE ----
+ * (renumbering, CSR(M) and CSR(M^T) in the solver's numbering, nnz-balanced row partition of both sides).  The CLI's
+ * main thread prepares for its G contexts; rank 0 of a multi-process job prepares, saves, and the other ranks load
+ * (mmap: one copy of the pages per node).  Saved next to the matrix it is the binary cache of SURVEY 8(f)1: a second
+ * run skips the renumbering and the CSR builds.  sequential/lanczos_modp.c:199-263 is what it stands in front of.
+ *   reorder        0 keep the file's numbering, 1 scored choice (blz_reorder_auto), 2 round 1's order
+ *   chunks         pieces per exchange (1 for one rank)
+ *   rows_per_line  block rows of the context per 128-byte line (128 / (width in HBM * word bytes), at least 1)
+ *   hot_cap        block rows the LDS panel can hold (0: none); only used with one rank and one piece
+ * `key` ties a cache file to its inputs (the CLI uses blz_file_hash of the matrix ^ prime, width, ranks, ...): a
+ * load with another key fails with BLZ_EFORMAT and the caller prepares afresh. */
+typedef struct blz_prepared blz_prepared;
+int blz_prepare(const blz_coo *M, int right, int nranks, int chunks, int reorder, int rows_per_line, int64_t hot_cap,
+		double min_share, blz_prepared **out);
+int blz_prepared_save(const blz_prepared *P, const char *path, uint64_t key);
+int blz_prepared_load(const char *path, uint64_t key, blz_prepared **out);
+void blz_prepared_free(blz_prepared *P);
+/* rank `rank`'s rows of M (t = 0) or of M^T (t = 1) as a CSR of its own, columns rewritten to positions in the gathered
+ * operand (what blz_shard_matrix returns in slabs[t]) */
+int blz_prepared_slab(const blz_prepared *P, int rank, int t, blz_csr *slab);
+/* 64-bit content hash of a file (0 on error) */
+uint64_t blz_file_hash(const char *path);
+
 /* What rank `rank` of `nranks` keeps of M for the solve (right=0: x*M=0, right=1: M*x=0).
  * "Side 0" is the row space of v/Av/p, "side 1" that of tmp (sequential/lanczos_modp.c:592-593).
  *   bounds0/bounds1 [nranks+1]  nnz-balanced row partition of each side
@@ -190,6 +213,16 @@ int blz_word_bytes(const blz_ctx *ctx);	/* 4 if prime < 2^32 else 8: width of a 
  * this rank's nnz-balanced row slabs, allocates the four blocks and zeroes them (:617-622).
  * rank/nranks = 0/1 for a single GPU. */
 int blz_set_matrix(blz_ctx *ctx, const blz_coo *M, int right, int rank, int nranks);
+
+/* The same with the rank-independent work done once and shared (blz_prepare / blz_prepared_load above):
+ *   blz_prepare_for   prepares M with the parameters THIS context wants (pieces per exchange from the slab sizes and
+ *                     BLZ_AG_CHUNKS, renumbering, panel capacity from its block width and word size)
+ *   blz_prepare_key   the cache key for those parameters and a content hash of the matrix
+ *   blz_set_matrix_prepared  cuts rank `rank`'s slabs out of P and uploads them (P stays the caller's) */
+int blz_prepare_for(const blz_ctx *c, const blz_coo *M, int right, int nranks, blz_prepared **out);
+uint64_t blz_prepare_key(const blz_ctx *c, uint64_t content_hash, int64_t mrows, int64_t mcols, int64_t nnz, int right,
+			 int nranks);
+int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int rank);
 /* The solver renumbers rows internally (blz_reorder; BLZ_NO_REORDER=1 disables it).  Nothing of it is visible
  * through this ABI: blz_set_block / blz_get_block / blz_init_v / checkpoints all speak the ORIGINAL row numbering,
  * and results are bit-identical either way.  With nranks > 1 a rank's slab is a set of original rows that need
@@ -252,6 +285,16 @@ int blz_set_iterations(blz_ctx *ctx, int64_t iterations);	/* --load-checkpoint *
 
 /* final_check(), :560-582, on V and on TMP (= M^T v of the last iteration). */
 int blz_final_check(blz_ctx *ctx, int *v_nonzero, int *vtm_zero);
+
+/* Asynchronous snapshot of (v, p, iteration count) for checkpoints (openMP/lanczos_modp.c:1013-1022 stops its loop
+ * for them).  blz_snapshot_begin, called between two blz_iterate calls, enqueues the device-to-host copies of this
+ * rank's rows on a stream of their own and returns; the GPU pauses for the transfer only and the caller goes on
+ * iterating.  blz_snapshot_wait blocks until the copies have landed and writes this rank's rows into v and p (whole
+ * blocks of rows(V) x n words, original numbering; other ranks' rows untouched).  It may be called from ANOTHER host
+ * thread (the checkpoint writer) while the owner is inside blz_iterate -- the one exception to one thread per handle.
+ * One snapshot in flight per context. */
+int blz_snapshot_begin(blz_ctx *c);
+int blz_snapshot_wait(blz_ctx *c, uint64_t *v, uint64_t *p, int64_t *iterations);
 
 /* Measurement: run one hot-path kernel `reps` times between two HIP events on the context's
  * stream and return the mean time.  which: 0 = first SpMV of an iteration (:635), 1 = second (:636, without

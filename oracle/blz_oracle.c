@@ -583,6 +583,96 @@ void orc_spmv_omp(u64 *y, const orc_coo *M, const u64 *x, int transpose, int n, 
 	free(priv);
 }
 
+/*
+ * The same product by rows: a CSR of M (or of M^T) built once, one output row per loop iteration, 128-bit sums
+ * in registers, one reduction per word.  No private copies of the output (orc_spmv_omp zeroes and sums
+ * nthreads x rows x n u128 words per call, which is what it spends most of its time on at 16 threads), so this
+ * is the form bench.py times as cpu_baseline; openMP/lanczos_modp.c:329-374 stays restated above.
+ */
+struct orc_csr {
+	int64_t rows, nnz;
+	int64_t *row_ptr;
+	int32_t *col;
+	uint32_t *val;
+};
+
+void orc_csr_free(orc_csr *A)
+{
+	if (!A)
+		return;
+	free(A->row_ptr);
+	free(A->col);
+	free(A->val);
+	free(A);
+}
+
+orc_csr *orc_csr_build(const orc_coo *M, int transpose)
+{
+	orc_csr *A = calloc(1, sizeof *A);
+	if (!A)
+		return NULL;
+	A->rows = transpose ? M->ncols : M->nrows;
+	A->nnz = M->nnz;
+	A->row_ptr = calloc((size_t)A->rows + 2, sizeof *A->row_ptr);
+	A->col = malloc(sizeof *A->col * (size_t)(M->nnz ? M->nnz : 1));
+	A->val = malloc(sizeof *A->val * (size_t)(M->nnz ? M->nnz : 1));
+	int64_t *fill = malloc(sizeof *fill * (size_t)(A->rows + 1));
+	if (!A->row_ptr || !A->col || !A->val || !fill) {
+		free(fill);
+		orc_csr_free(A);
+		return NULL;
+	}
+	for (int64_t k = 0; k < M->nnz; k++)
+		A->row_ptr[(transpose ? M->j[k] : M->i[k]) + 1]++;
+	for (int64_t r = 0; r < A->rows; r++)
+		A->row_ptr[r + 1] += A->row_ptr[r];
+	memcpy(fill, A->row_ptr, sizeof *fill * (size_t)(A->rows + 1));
+	for (int64_t k = 0; k < M->nnz; k++) {
+		const int64_t at = fill[transpose ? M->j[k] : M->i[k]]++;
+		A->col[at] = (int32_t)(transpose ? M->i[k] : M->j[k]);
+		A->val[at] = (uint32_t)M->x[k];
+	}
+	free(fill);
+	return A;
+}
+
+void orc_spmv_csr_omp(u64 *y, const orc_csr *A, const u64 *x, int n, u64 p, int nthreads)
+{
+	const int T = pick_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 2048) num_threads(T)
+	for (int64_t r = 0; r < A->rows; r++) {
+		u128 acc[64];	/* n <= 64 (BLZ_MAX_N) */
+		for (int l = 0; l < n; l++)
+			acc[l] = 0;
+		for (int64_t k = A->row_ptr[r]; k < A->row_ptr[r + 1]; k++) {
+			const u64 a = A->val[k];
+			const u64 *xc = x + (int64_t)A->col[k] * n;
+			for (int l = 0; l < n; l++)
+				acc[l] += (u128)a * xc[l];
+		}
+		for (int l = 0; l < n; l++)
+			y[r * n + l] = (u64)(acc[l] % p);
+	}
+}
+
+int orc_iteration_csr_omp(const orc_csr *A, const orc_csr *At, int64_t nrows, int n, u64 p, int right, u64 *v, u64 *tmp,
+			  u64 *Av, u64 *pblk, int nthreads)
+{
+	/* sequential/lanczos_modp.c:635-656 with tmp = (right ? M : M^T) v, Av = (right ? M^T : M) tmp */
+	u64 *sm = malloc(sizeof(u64) * (size_t)(3 * n * n + n));
+	u64 *vtAv = sm, *vtAAv = sm + n * n, *winv = sm + 2 * n * n, *d = sm + 3 * n * n;
+	orc_spmv_csr_omp(tmp, right ? A : At, v, n, p, nthreads);
+	orc_spmv_csr_omp(Av, right ? At : A, tmp, n, p, nthreads);
+	orc_block_dot_omp(vtAv, vtAAv, nrows, Av, v, n, p, nthreads);
+	const int npiv = orc_semi_inverse(vtAv, winv, d, n, p);
+	if (npiv) {
+		orc_orthogonalize_omp(v, tmp, pblk, d, vtAv, vtAAv, winv, nrows, Av, n, p, nthreads);
+		memcpy(v, tmp, sizeof(u64) * (size_t)(nrows * n));
+	}
+	free(sm);
+	return npiv;
+}
+
 /* openMP/lanczos_modp.c:681-712: per-thread n x n partials, combined once. */
 void orc_block_dot_omp(u64 *vtAv, u64 *vtAAv, int64_t N, const u64 *Av, const u64 *v, int n, u64 p,
 		       int nthreads)

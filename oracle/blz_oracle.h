@@ -105,6 +105,14 @@ void orc_block_dot_omp(uint64_t *vtAv, uint64_t *vtAAv, int64_t N, const uint64_
 void orc_orthogonalize_omp(const uint64_t *v, uint64_t *tmp, uint64_t *pblk, const uint64_t *d,
 			   const uint64_t *vtAv, const uint64_t *vtAAv, const uint64_t *winv,
 			   int64_t N, const uint64_t *Av, int n, uint64_t p, int nthreads);
+/* The same product by rows of a CSR built once (no per-thread copies of the output): the form bench.py times. */
+typedef struct orc_csr orc_csr;
+orc_csr *orc_csr_build(const orc_coo *M, int transpose);
+void orc_csr_free(orc_csr *A);
+void orc_spmv_csr_omp(uint64_t *y, const orc_csr *A, const uint64_t *x, int n, uint64_t p, int nthreads);
+/* A = CSR of M, At = CSR of M^T; nrows = rows of v */
+int orc_iteration_csr_omp(const orc_csr *A, const orc_csr *At, int64_t nrows, int n, uint64_t p, int right,
+			  uint64_t *v, uint64_t *tmp, uint64_t *Av, uint64_t *pblk, int nthreads);
 /* One full iteration with the OpenMP kernels; returns npiv. v is updated in place. */
 int orc_iteration_omp(const orc_coo *M, int n, uint64_t p, int right, uint64_t *v, uint64_t *tmp,
 		      uint64_t *Av, uint64_t *pblk, int nthreads);

@@ -44,6 +44,7 @@ def lib():
         L.orc_block_lanczos.restype = C.c_int
         L.orc_final_check.restype = C.c_int
         L.orc_iteration_omp.restype = C.c_int
+        L.orc_iteration_csr_omp.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -189,6 +190,40 @@ def check_kernel(matrix_path, kernel_path, prime, right=False):
     rc = lib().orc_check_kernel(matrix_path.encode(), kernel_path.encode(), C.c_uint64(prime),
                                 C.c_int(int(right)), err, 256)
     return rc, err.value.decode()
+
+
+class CsrPair:
+    """CSR of M and of M^T for the by-rows OpenMP iteration (orc_iteration_csr_omp)."""
+
+    def __init__(self, M):
+        L = lib()
+        L.orc_csr_build.restype = C.c_void_p
+        L.orc_csr_free.argtypes = [C.c_void_p]
+        L.orc_csr_free.restype = None
+        self.nrows, self.ncols = M.nrows, M.ncols
+        self.a = L.orc_csr_build(C.byref(M.c), C.c_int(0))
+        self.at = L.orc_csr_build(C.byref(M.c), C.c_int(1))
+        if not self.a or not self.at:
+            raise MemoryError("orc_csr_build")
+
+    def spmv(self, x, transpose, n, prime, threads=0):
+        rows = self.ncols if transpose else self.nrows
+        y = np.zeros(rows * n, dtype=np.uint64)
+        lib().orc_spmv_csr_omp(ptr(y), C.c_void_p(self.at if transpose else self.a), ptr(u64(x)), C.c_int(n),
+                               C.c_uint64(prime), C.c_int(threads))
+        return y
+
+    def iteration(self, n, prime, right, v, tmp, Av, pblk, threads=0):
+        nrows = self.ncols if right else self.nrows
+        return lib().orc_iteration_csr_omp(C.c_void_p(self.a), C.c_void_p(self.at), C.c_int64(nrows), C.c_int(n),
+                                           C.c_uint64(prime), C.c_int(int(right)), ptr(v), ptr(tmp), ptr(Av), ptr(pblk),
+                                           C.c_int(threads))
+
+    def close(self):
+        for h in (self.a, self.at):
+            if h:
+                lib().orc_csr_free(C.c_void_p(h))
+        self.a = self.at = None
 
 
 def iteration_omp(M, n, prime, right, v, tmp, Av, pblk, threads=0):

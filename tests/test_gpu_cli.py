@@ -172,3 +172,66 @@ def test_gpus_flag_reports_missing_devices_cleanly():
     r = subprocess.run([EXE, "--matrix", mt, "--prime", "65537", "--n", "4", "--gpus", str(have + 1)],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "GPU" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_cache_of_the_prepared_matrix_is_reused_and_changes_nothing(tmp_path):
+    """--cache keeps the renumbered CSR(M), CSR(M^T) and the partition next to the matrix: the second run
+    maps it instead of rebuilding, and both write the file the reference binary writes; another prime gets its own cache."""
+    cli = json.load(open(os.path.join(GOLDEN, "cli.json")))
+    c = cli["rand3000x2000_p1073741789_n8_left"] if "rand3000x2000_p1073741789_n8_left" in cli else None
+    tag = next(t for t, q in cli.items() if t != "_validation" and q["matrix"] == "rand3000x2000")
+    c = cli[tag]
+    mpath = str(tmp_path / "m.mtx")
+    shutil.copy(os.path.join(GOLDEN, "rand3000x2000.mtx"), mpath)
+    args = ["--matrix", mpath, "--prime", str(c["prime"]), "--n", str(c["n"]), "--cache"] + (["--right"] if c["right"] else [])
+    outs = []
+    for k in range(2):
+        out = str(tmp_path / f"k{k}.mtx")
+        r = run(args + ["--output-file", out])
+        assert r.returncode == 0, r.stderr
+        assert ("mapped from" in r.stderr) == (k == 1), r.stderr
+        assert ("saved to" in r.stderr) == (k == 0), r.stderr
+        outs.append(hashlib.sha256(open(out, "rb").read()).hexdigest())
+    assert outs[0] == outs[1] == c["out_sha256"]
+    caches = [f for f in os.listdir(tmp_path) if f.endswith(".blzcache")]
+    assert len(caches) == 1
+    r = run(["--matrix", mpath, "--prime", "65537", "--n", str(c["n"]), "--cache", "--stop-after", "3"])
+    assert r.returncode == 0 and "mapped from" not in r.stderr
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".blzcache")]) == 2
+
+
+@pytest.mark.gpu
+def test_asynchronous_snapshot_is_the_state_at_the_moment_it_was_begun():
+    """blz_snapshot_begin between two batches, more iterations enqueued behind it, blz_snapshot_wait afterwards (from
+    another thread, as the CLI's checkpoint writer does): the snapshot holds v, p of the iteration it was begun at, and
+    the solve is not disturbed."""
+    import sys
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import blz
+    import oracle as orc
+    p, n = (1 << 61) - 1, 8
+    path = os.path.join(GOLDEN, "rand3000x2000.mtx")
+    M, Mo = blz.Matrix.load(path, p), orc.Matrix.load(path, p)
+    at5 = orc.block_lanczos(Mo, n, p, stop_after=5)
+    at12 = orc.block_lanczos(Mo, n, p, stop_after=12)
+    for width in (8, 3):                                   # padded width in HBM (3 -> 4) unpacks to the caller's width
+        if width != n:
+            at5 = orc.block_lanczos(Mo, width, p, stop_after=5)
+            at12 = orc.block_lanczos(Mo, width, p, stop_after=12)
+        with blz.Context(p, width) as ctx:
+            ctx.set_matrix(M, False)
+            ctx.init_v()
+            ctx.iterate(5)
+            ctx.snapshot_begin()
+            with pytest.raises(blz.BlzError):
+                ctx.snapshot_begin()                       # one in flight
+            got = {}
+            th = threading.Thread(target=lambda: got.update(zip(("v", "p", "its"), ctx.snapshot_wait())))
+            th.start()
+            ctx.iterate(7)
+            th.join(60)
+            assert got["its"] == 5 and np.array_equal(got["v"], at5["v"]) and np.array_equal(got["p"], at5["p"])
+            assert np.array_equal(ctx.get_block(blz.V), at12["v"]) and np.array_equal(ctx.get_block(blz.P), at12["p"])

@@ -254,3 +254,36 @@ def test_renumbering_is_chosen_by_the_lines_it_leaves_to_fetch():
     Bs = blz.Matrix(60000, 64000, pr[B.i], B.j, B.x)
     rp_s, cp_s, _, _, loc_s, kind_s = blz.reorder_auto(Bs)
     assert np.array_equal(np.sort(rp_s), np.arange(60000)) and kind_s in (1, 2) and max(loc_s) < 0.5
+
+
+@pytest.mark.parametrize("nranks,chunks,right", [(1, 1, False), (2, 1, True), (3, 4, False)])
+def test_prepared_matrix_is_what_every_rank_used_to_build_and_survives_the_cache(tmp_path, nranks, chunks, right):
+    """blz_prepare does the rank-independent set-up once; blz_prepared_slab cuts a rank's slabs out of it -- the same slabs
+    blz_shard_matrix built per rank from the renumbered matrix -- and a save / load round trip through the cache file
+    (mmapped) gives the same slabs; a wrong key is refused."""
+    p = (1 << 61) - 1
+    M = blz.Matrix.load(os.path.join(GOLDEN, "rand3000x2000.mtx"), p)
+    path = str(tmp_path / "m.blzcache")
+    with blz.Prepared.prepare(M, right, nranks, chunks, reorder=1) as P:
+        P.save(path, 0xABCDEF)
+        fresh = [[P.slab(g, t) for t in (0, 1)] for g in range(nranks)]
+    rp, cp = blz.reorder_auto(M)[:2]
+    R = blz.Matrix(M.nrows, M.ncols, rp[M.i], cp[M.j], M.x)
+    for g in range(nranks):
+        want = blz.shard_matrix(R, right, g, nranks, chunks)["slabs"]
+        for t in (0, 1):
+            for k_ in ("rows", "cols", "nnz"):
+                assert fresh[g][t][k_] == want[t][k_]
+            for k_ in ("row_ptr", "col_idx", "val"):
+                assert np.array_equal(fresh[g][t][k_], want[t][k_]), (g, t, k_)
+    with blz.Prepared.load(path, 0xABCDEF) as L:
+        for g in range(nranks):
+            for t in (0, 1):
+                got = L.slab(g, t)
+                for k_ in ("row_ptr", "col_idx", "val"):
+                    assert np.array_equal(got[k_], fresh[g][t][k_])
+    with pytest.raises(blz.BlzError) as e:
+        blz.Prepared.load(path, 0xABCDEE)
+    assert e.value.code == blz.EFORMAT
+    h1 = blz.file_hash(os.path.join(GOLDEN, "rand3000x2000.mtx"))
+    assert h1 == blz.file_hash(os.path.join(GOLDEN, "rand3000x2000.mtx")) != blz.file_hash(os.path.join(GOLDEN, "rand300x200.mtx"))

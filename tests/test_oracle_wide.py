@@ -147,3 +147,24 @@ def test_omp_kernels_equal_sequential_at_wide_prime():
         np.zeros(M.nrows * n, np.uint64)
     assert orc.iteration_omp(M, n, p, False, vv, tt, aa, pp, 4) > 0
     assert np.array_equal(vv, res["v"]) and np.array_equal(pp, res["p"])
+
+
+@pytest.mark.parametrize("p,n,right", [(P61, 8, False), (1073741789, 4, True), ((1 << 62) - 57, 3, False)])
+def test_by_rows_omp_iteration_equals_sequential(p, n, right):
+    """orc_iteration_csr_omp (CSR built once, one output row per loop iteration, no per-thread copies of the output):
+    the form bench.py times as cpu_baseline.  Same words as the sequential restatement, for both products and over
+    several whole iterations."""
+    M = orc.Matrix.load(os.path.join(GOLDEN, "rand3000x2000.mtx"), p)
+    pair = orc.CsrPair(M)
+    rows_v = M.ncols if right else M.nrows
+    x = orc.init_v(M.ncols, n, p)
+    assert np.array_equal(pair.spmv(x, False, n, p, 4), orc.spmv(M, x, False, n, p))
+    y = orc.init_v(M.nrows, n, p)
+    assert np.array_equal(pair.spmv(y, True, n, p, 3), orc.spmv(M, y, True, n, p))
+    want = orc.block_lanczos(M, n, p, right=right, stop_after=4)
+    v = orc.init_v(rows_v, n, p)
+    tmp, Av, pb = np.zeros(max(M.nrows, M.ncols) * n, np.uint64), np.zeros(rows_v * n, np.uint64), np.zeros(rows_v * n, np.uint64)
+    for _ in range(4):
+        assert pair.iteration(n, p, right, v, tmp, Av, pb, 4) > 0
+    pair.close()
+    assert np.array_equal(v, want["v"]) and np.array_equal(pb, want["p"])

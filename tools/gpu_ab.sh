@@ -14,7 +14,7 @@ tail -15 "$out/pytest.log"
 [ $rc -eq 0 ] || exit $rc
 for w in $wl; do
 	for st in 0 1; do
-		BLZ_NO_STAGE=$st timeout -k 10 300 python bench.py --workload $w --cpu-seconds 0 --ref-iterations 0 > "$out/bench_${w}_nostage$st.json" 2> "$out/bench_${w}_nostage$st.err" || { echo "bench $w $st failed"; tail -5 "$out/bench_${w}_nostage$st.err"; exit 1; }
+		BLZ_NO_STAGE=$st timeout -k 10 300 python bench.py --workload $w --cpu-seconds 0 --ref-iterations 0 --extras 0 > "$out/bench_${w}_nostage$st.json" 2> "$out/bench_${w}_nostage$st.err" || { echo "bench $w $st failed"; tail -5 "$out/bench_${w}_nostage$st.err"; exit 1; }
 		python3 - "$out/bench_${w}_nostage$st.json" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))

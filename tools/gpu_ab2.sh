@@ -10,7 +10,7 @@ for w in "$@"; do
 	i=0
 	for e in "$envA" "$envB"; do
 		i=$((i + 1))
-		env $e timeout -k 10 300 python bench.py --workload $w --cpu-seconds 0 --ref-iterations 0 > "$out/bench_${w}_$i.json" 2> "$out/bench_${w}_$i.err" || { echo "bench $w [$e] failed"; tail -5 "$out/bench_${w}_$i.err"; exit 1; }
+		env $e timeout -k 10 300 python bench.py --workload $w --cpu-seconds 0 --ref-iterations 0 --extras 0 > "$out/bench_${w}_$i.json" 2> "$out/bench_${w}_$i.err" || { echo "bench $w [$e] failed"; tail -5 "$out/bench_${w}_$i.err"; exit 1; }
 		python3 - "$out/bench_${w}_$i.json" "$e" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))

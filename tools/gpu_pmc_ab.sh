@@ -18,7 +18,7 @@ for e in "$envA" "$envB"; do
 	           "VALUBusy MemUnitStalled MeanOccupancyPerCU" \
 	           "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD"; do
 		i=$((i + 1))
-		timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- python3 bench.py "$@" --cpu-seconds 0 --ref-iterations 0 > "$out/bench_pass$i.json" 2> "$out/pass$i.err" || { echo "pass $i ($set) failed"; tail -5 "$out/pass$i.err"; }
+		timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- python3 bench.py "$@" --cpu-seconds 0 --ref-iterations 0 --extras 0 > "$out/bench_pass$i.json" 2> "$out/pass$i.err" || { echo "pass $i ($set) failed"; tail -5 "$out/pass$i.err"; }
 	done
 	echo "== [$e] ==" > "$out/pmc_summary.txt"
 	python3 tools/pmc_summary.py "$out" k_spmv >> "$out/pmc_summary.txt" 2>&1

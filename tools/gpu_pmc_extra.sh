@@ -16,7 +16,7 @@ for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA
            "VALUBusy MemUnitStalled MeanOccupancyPerCU" \
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_UTCL1_TRANSLATION_MISS_sum"; do
 	i=$((i + 1))
-	rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- python3 bench.py "$@" --cpu-seconds 0 --ref-iterations 0 > "$out/bench_pass$i.json" 2> "$out/pass$i.err" || { echo "pass $i ($set) failed"; tail -5 "$out/pass$i.err"; }
+	rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- python3 bench.py "$@" --cpu-seconds 0 --ref-iterations 0 --extras 0 > "$out/bench_pass$i.json" 2> "$out/pass$i.err" || { echo "pass $i ($set) failed"; tail -5 "$out/pass$i.err"; }
 done
 python3 tools/pmc_summary.py "$out" k_spmv k_orthogonalize k_block_dot > "$out/pmc_summary.txt" 2>&1
 cat "$out/pmc_summary.txt"

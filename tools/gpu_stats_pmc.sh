@@ -9,8 +9,8 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cd "$root"
 for kv in $e; do export "$kv"; done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py "$@" --cpu-seconds 0 --ref-iterations 0 > "$out/bench_stats.json" 2> "$out/stats.err" || { echo "stats pass failed"; tail -5 "$out/stats.err"; exit 1; }
-timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$out/pmc1" -- python3 bench.py "$@" --cpu-seconds 0 --ref-iterations 0 > "$out/bench_pmc1.json" 2> "$out/pmc1.err" || { echo "pmc pass failed"; tail -5 "$out/pmc1.err"; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py "$@" --cpu-seconds 0 --ref-iterations 0 --extras 0 > "$out/bench_stats.json" 2> "$out/stats.err" || { echo "stats pass failed"; tail -5 "$out/stats.err"; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$out/pmc1" -- python3 bench.py "$@" --cpu-seconds 0 --ref-iterations 0 --extras 0 > "$out/bench_pmc1.json" 2> "$out/pmc1.err" || { echo "pmc pass failed"; tail -5 "$out/pmc1.err"; }
 echo "== [$e] $@ ==" > "$out/summary.txt"
 python3 tools/summarize_prof.py "$out" >> "$out/summary.txt" 2>&1
 python3 tools/pmc_summary.py "$out" k_spmv >> "$out/summary.txt" 2>&1
