@@ -179,11 +179,9 @@ def test_cache_of_the_prepared_matrix_is_reused_and_changes_nothing(tmp_path):
     """--cache keeps the renumbered CSR(M), CSR(M^T) and the partition next to the matrix: the second run
     maps it instead of rebuilding, and both write the file the reference binary writes; another prime gets its own cache."""
     cli = json.load(open(os.path.join(GOLDEN, "cli.json")))
-    c = cli["rand3000x2000_p1073741789_n8_left"] if "rand3000x2000_p1073741789_n8_left" in cli else None
-    tag = next(t for t, q in cli.items() if t != "_validation" and q["matrix"] == "rand3000x2000")
-    c = cli[tag]
+    c = cli["rand300x200_p65537_n4_right"]
     mpath = str(tmp_path / "m.mtx")
-    shutil.copy(os.path.join(GOLDEN, "rand3000x2000.mtx"), mpath)
+    shutil.copy(os.path.join(GOLDEN, c["matrix"] + ".mtx"), mpath)
     args = ["--matrix", mpath, "--prime", str(c["prime"]), "--n", str(c["n"]), "--cache"] + (["--right"] if c["right"] else [])
     outs = []
     for k in range(2):
@@ -196,7 +194,7 @@ def test_cache_of_the_prepared_matrix_is_reused_and_changes_nothing(tmp_path):
     assert outs[0] == outs[1] == c["out_sha256"]
     caches = [f for f in os.listdir(tmp_path) if f.endswith(".blzcache")]
     assert len(caches) == 1
-    r = run(["--matrix", mpath, "--prime", "65537", "--n", str(c["n"]), "--cache", "--stop-after", "3"])
+    r = run(["--matrix", mpath, "--prime", "1073741789", "--n", str(c["n"]), "--cache", "--stop-after", "3"])
     assert r.returncode == 0 and "mapped from" not in r.stderr
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".blzcache")]) == 2
 
