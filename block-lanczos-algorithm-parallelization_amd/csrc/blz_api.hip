@@ -40,6 +40,7 @@ struct Rccl {
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
 	ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -69,6 +70,7 @@ int rccl_load()
 	SYM(CommDestroy, "ncclCommDestroy")
 	SYM(AllGather, "ncclAllGather")
 	SYM(AllReduce, "ncclAllReduce")
+	SYM(ReduceScatter, "ncclReduceScatter")
 	SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
 	g_rccl.handle = h;
@@ -84,7 +86,7 @@ int rccl_load()
 
 }  // namespace
 
-enum { PK_SPMV1 = 0, PK_SPMV2, PK_DOT, PK_SEMI, PK_ORTHO, PK_AG_V, PK_AG_T, PK_AR, PK_COUNT };
+enum { PK_SPMV1 = 0, PK_SPMV2, PK_DOT, PK_SEMI, PK_ORTHO, PK_AG_V, PK_AG_T, PK_AR, PK_RS, PK_COUNT };
 
 struct ProfSpan {
 	int cls;
@@ -138,6 +140,12 @@ struct blz_ctx {
 	size_t snap_bytes = 0;
 	bool snap_pending = false;
 	int64_t snap_iterations = 0;
+	/* short-side exchange (tall / wide matrices on several ranks): product t multiplies the transpose of this rank's rows
+	 * of the other orientation by its OWN slab and reduce-scatters the full-length partial products */
+	bool short_side[2] = { false, false };
+	DevCsr csr_short[2];
+	void *part = nullptr;		/* partial product, nranks x stride[output side] rows (u64 words) */
+	size_t part_bytes = 0;
 	double hot_share[2] = { 0.0, 0.0 };	/* share of the entries held by the rows / columns numbered first */
 	double locality[2] = { 1.0, 1.0 };	/* lines per gathered entry in windows of rows, product M*x / M^T*x */
 	int order_kind = 0;			/* which order blz_reorder_auto chose */
@@ -305,6 +313,9 @@ extern "C" void blz_destroy(blz_ctx *c)
 	for (int t = 0; t < 2; t++)
 		for (auto &A : c->csr[t])
 			free_csr(A);
+	for (auto &A : c->csr_short)
+		free_csr(A);
+	if (c->part) hipFree(c->part);
 	for (void *&b : c->slab)
 		if (b) hipFree(b);
 	for (void *&b : c->gath)
@@ -563,7 +574,28 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 		c->csr[t].assign((size_t)K, DevCsr{});
 	}
 	int rc = BLZ_OK;
+	/* Short-side form of a product whose operand side is at least 8 times longer than its output side (64-bit words:
+	 * the partial sums travel as u64).  BLZ_SHORT_SIDE=0 / 1 forces it off / on (tests, A/B). */
+	size_t part_need = 0;
+	for (int t = 0; t < 2; t++) {
+		free_csr(c->csr_short[t]);
+		const int rs_t = c->row_side[t], cs_t = 1 - rs_t;
+		bool on = (nranks > 1 || c->force_comm) && c->cfg.word == 8 && c->glob_rows[cs_t] >= 8 * c->glob_rows[rs_t];
+		if (const char *e = getenv("BLZ_SHORT_SIDE"))
+			on = e[0] == '1' && c->cfg.word == 8 && (nranks > 1 || c->force_comm);
+		c->short_side[t] = on;
+		if (on)
+			part_need = std::max(part_need, (size_t)nranks * (size_t)std::max<int64_t>(c->stride[rs_t], 1) * c->cfg.n * 8);
+	}
 	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
+		if (c->short_side[t]) {
+			blz_csr sh;
+			if ((rc = blz_prepared_slab_short(P, rank, t, &sh)) != BLZ_OK)
+				break;
+			rc = upload_csr(c, sh, c->csr_short[t]);
+			blz_csr_free(&sh);
+			continue;		/* the gathering form of this product is not uploaded at all */
+		}
 		blz_csr slab;
 		memset(&slab, 0, sizeof slab);
 		const bool whole = nranks == 1;		/* one rank: the slab IS the prepared CSR, no copy */
@@ -596,6 +628,13 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 	if (rc != BLZ_OK)
 		return rc;
 
+	if (part_need > c->part_bytes) {
+		if (c->part)
+			hipFree(c->part);
+		c->part = nullptr;
+		HIPCHK(hipMalloc(&c->part, part_need));
+		c->part_bytes = part_need;
+	}
 	const int64_t slab_rows = std::max<int64_t>(std::max(c->stride[0], c->stride[1]), 1);
 	const size_t bytes = (size_t)slab_rows * c->cfg.n * c->cfg.word;
 	for (int b = 0; b < 4; b++) {
@@ -611,7 +650,9 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 			hipFree(c->gath[sd]);
 		c->gath[sd] = nullptr;
 		c->gath_holds[sd] = -1;
-		if (nranks > 1) {
+		/* side sd is gathered by the product whose rows live on the other side; in its short-side form nothing is */
+		const int t_gath = c->row_side[0] == 1 - sd ? 0 : 1;
+		if (nranks > 1 && !c->short_side[t_gath]) {
 			const size_t gb = (size_t)std::max<int64_t>(c->stride[sd], 1) * nranks * c->cfg.n * c->cfg.word;
 			HIPCHK(hipMalloc(&c->gath[sd], gb));
 			HIPCHK(hipMemset(c->gath[sd], 0, gb));
@@ -664,6 +705,8 @@ extern "C" int64_t blz_local_nnz(const blz_ctx *c, int transpose)
 	if (!c || !c->have_matrix)
 		return -1;
 	int64_t nnz = 0;
+	if (c->short_side[transpose ? 1 : 0])
+		return c->csr_short[transpose ? 1 : 0].nnz;
 	for (const auto &A : c->csr[transpose ? 1 : 0])
 		nnz += A.nnz;
 	return nnz;
@@ -762,6 +805,32 @@ static int get_rows(blz_ctx *c, uint64_t *dst, const void *src, int64_t rows)
 		HIPCHK(hipSetDevice((c)->device));                                      \
 	} while (0)
 
+extern "C" int blz_short_side(const blz_ctx *c, int transpose)
+{
+	return (c && c->have_matrix) ? (int)c->short_side[transpose ? 1 : 0] : -1;
+}
+
+/* the full-length partial product a short-side blz_spmv left behind (external-exchange mode: the caller does the
+ * reduce-scatter): rows(dst side) x n words in the ORIGINAL numbering, sums not yet reduced mod p */
+extern "C" int blz_get_partial(blz_ctx *c, int transpose, uint64_t *host)
+{
+	NEED_MATRIX(c);
+	const int t = transpose ? 1 : 0;
+	if (!host || !c->short_side[t])
+		return blz_fail(BLZ_EINVAL, "blz_get_partial: product %d is not in the short-side form", t);
+	HIPCHK(hipStreamSynchronize(c->stream));
+	const int rs_t = c->row_side[t], np = c->cfg.n, un = c->un;
+	std::vector<uint64_t> pad((size_t)c->nranks * c->stride[rs_t] * np);
+	HIPCHK(hipMemcpy(pad.data(), c->part, pad.size() * 8, hipMemcpyDeviceToHost));
+	for (int g = 0; g < c->nranks; g++)
+		for (int64_t q = 0; q < c->bounds[rs_t][g + 1] - c->bounds[rs_t][g]; q++) {
+			const int64_t solver_row = c->bounds[rs_t][g] + q;
+			const int64_t orig = c->inv[rs_t].empty() ? solver_row : c->inv[rs_t][(size_t)solver_row];
+			memcpy(host + (size_t)orig * un, pad.data() + ((size_t)g * c->stride[rs_t] + q) * np, (size_t)un * 8);
+		}
+	return BLZ_OK;
+}
+
 /* host block in ORIGINAL numbering -> one contiguous array in the solver's numbering (and back) */
 static void to_solver_order(const blz_ctx *c, int sd, const uint64_t *host, uint64_t *out)
 {
@@ -792,8 +861,8 @@ extern "C" int blz_set_block(blz_ctx *c, int block, const uint64_t *host)
 	HIPCHK(hipStreamSynchronize(c->xstream));
 	/* this rank's rows */
 	int rc = put_rows(c, c->slab[block], src + c->first[sd] * n, c->count[sd]);
-	if (rc != BLZ_OK || c->nranks == 1)
-		return rc;
+	if (rc != BLZ_OK || c->nranks == 1 || !c->gath[sd])
+		return rc;	/* (a side whose product runs in the short-side form has no gathered copy) */
 	/* and, with several ranks, the whole gathered operand (an all-gather done by the caller): piece k of rank g
 	 * sits at (k * nranks + g) * piece rows */
 	const int K = (int)c->csr[0].size();
@@ -969,9 +1038,31 @@ static inline u64 *dot_out(blz_ctx *c) { return exchanging(c) ? c->dot_send : c-
  */
 static int enqueue_product(blz_ctx *c, int transpose, int src, int dst, bool with_dot, int *nb)
 {
-	const int K = (int)c->csr[transpose].size(), sd = side_of(src);
 	const bool xchg = exchanging(c);
 	const int cls = transpose == !c->right ? PK_SPMV1 : PK_SPMV2;
+	if (c->short_side[transpose]) {
+		/* partial product of this rank's own rows of the operand, full length on the output side; reduce-scatter of the
+		 * u64 sums; mod p.  Nothing is gathered. */
+		const int rs_t = c->row_side[transpose];
+		if (with_dot)
+			return blz_fail(BLZ_EINVAL, "enqueue_product: the short-side form has no fused inner products");
+		{
+			Span sp(c, cls);
+			HIPCHK(launch_spmv(c->cfg, c->csr_short[transpose], slab_ptr(c, src), c->part, 0, c->ctl, c->stream));
+		}
+		if (xchg) {
+			if (!c->comm)
+				return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
+			{
+				Span sp(c, PK_RS);
+				NCCLCHK(g_rccl.ReduceScatter(c->part, c->slab[dst], (size_t)c->stride[rs_t] * c->cfg.n, ncclUint64, ncclSum,
+							     c->comm, c->stream));
+			}
+			HIPCHK(launch_reduce_modp(c->cfg, c->slab[dst], c->count[rs_t] * c->cfg.n, c->ctl, c->stream));
+		}
+		return BLZ_OK;
+	}
+	const int K = (int)c->csr[transpose].size(), sd = side_of(src);
 	if (xchg) {
 		if (!c->comm)
 			return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
@@ -1107,7 +1198,7 @@ static int enqueue_iteration(blz_ctx *c)
 {
 	int rc;
 	if ((rc = enqueue_product(c, !c->right, BLZ_V, BLZ_TMP, false, nullptr)) != BLZ_OK) return rc;	/* :635 */
-	if (c->fuse_dot && spmv_dot_supported(c->cfg) && c->count[0] > 0) {
+	if (c->fuse_dot && spmv_dot_supported(c->cfg) && c->count[0] > 0 && !c->short_side[c->right]) {
 		int nb = 0;							/* :636 + :640 in one kernel */
 		if ((rc = enqueue_product(c, c->right, BLZ_TMP, BLZ_AV, true, &nb)) != BLZ_OK) return rc;
 		{

@@ -113,6 +113,9 @@ hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int 
 hipError_t launch_orthogonalize(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows,
 				const u64 *small, const DevCtl *ctl, hipStream_t s);
 
+/* X[i] <- X[i] mod p for 64-bit words that hold sums of a few residues (after a reduce-scatter) */
+hipError_t launch_reduce_modp(const KernelCfg &c, void *X, int64_t words, const DevCtl *ctl, hipStream_t s);
+
 /* flag |= any(X != 0) over `words` words */
 hipError_t launch_any_nonzero(const KernelCfg &c, const void *X, int64_t words, int *flag, hipStream_t s);
 

@@ -2317,6 +2317,31 @@ __global__ void __launch_bounds__(BLOCK) k_any_nonzero(const W *__restrict__ X, 
 		atomicOr(flag, 1);
 }
 
+/* x <- x mod p, words that are sums of a few residues (the reduce-scatter of partial products) */
+template <int MERS>
+__global__ void __launch_bounds__(BLOCK)
+k_reduce_modp(u64 *__restrict__ x, long long words, ModP m, const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	const long long step = (long long)gridDim.x * BLOCK;
+	for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < words; i += step)
+		x[i] = reduce128<MERS>(0, x[i], m);
+}
+
+hipError_t launch_reduce_modp(const KernelCfg &c, void *X, int64_t words, const DevCtl *ctl, hipStream_t s)
+{
+	if (words <= 0 || c.word != 8)
+		return c.word == 8 ? hipSuccess : hipErrorInvalidValue;
+	long long blocks = (words + BLOCK * 4 - 1) / (BLOCK * 4);
+	blocks = blocks < 1 ? 1 : (blocks > (long long)c.num_cu * 8 ? (long long)c.num_cu * 8 : blocks);
+	if (c.mers == 61)
+		hipLaunchKernelGGL((k_reduce_modp<61>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (u64 *)X, (long long)words, c.m, ctl);
+	else
+		hipLaunchKernelGGL((k_reduce_modp<0>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (u64 *)X, (long long)words, c.m, ctl);
+	return hipGetLastError();
+}
+
 hipError_t launch_any_nonzero(const KernelCfg &c, const void *X, int64_t words, int *flag, hipStream_t s)
 {
 	if (words == 0)

@@ -1270,6 +1270,92 @@ int blz_prepared_slab(const blz_prepared *P, int rank, int t, blz_csr *slab)
 	return rc;
 }
 
+/*
+ * Short-side exchange (tall or wide matrices, several ranks).  Product t of the iteration normally all-gathers its
+ * operand -- the block on side cs -- and every rank multiplies its rows of the matrix by all of it.  When side cs is much
+ * longer than the output side rs (relat9: 12.36 M rows against 0.55 M), that all-gather moves almost the whole long
+ * block into every GPU.  The other way round costs a block of the SHORT side: rank g multiplies the transpose of ITS
+ * rows of the other orientation, (full[1-t][own rows of side cs, :])^T, by its own slab of the operand -- no exchange
+ * at all going in -- which gives a full-length partial product on side rs, and a reduce-scatter (u64 sums, then mod p)
+ * hands every rank its rows of the sum.  mpi/lanczos_modp.c:1108-1124 is the reference's (hub-shaped) version of that
+ * reduction.  This builds the matrix of that product: rows = the padded rank-major numbering of side rs
+ * (nranks x stride[rs], so that equal-count reduce-scatter pieces are the ranks' slabs), columns = row numbers inside
+ * this rank's slab of side cs.
+ */
+int blz_prepared_slab_short(const blz_prepared *P, int rank, int t, blz_csr *out)
+{
+	if (!P || !out || rank < 0 || rank >= P->nranks || t < 0 || t > 1)
+		return blz_fail(BLZ_EINVAL, "blz_prepared_slab_short: bad argument");
+	memset(out, 0, sizeof *out);
+	const int rs = t == 0 ? (P->right ? 1 : 0) : (P->right ? 0 : 1), cs = 1 - rs;
+	const blz_csr *O = &P->full[1 - t];		/* rows on side cs, columns on side rs */
+	const int64_t b0 = P->bounds[cs][rank], b1 = P->bounds[cs][rank + 1];
+	const uint32_t k0 = O->row_ptr[b0], k1 = O->row_ptr[b1];
+	const int64_t nnz = (int64_t)k1 - k0, rows = (int64_t)P->nranks * P->stride[rs];
+	if (rows >= (int64_t)UINT32_MAX)
+		return blz_fail(BLZ_EINVAL, "blz_prepared_slab_short: too many rows");
+	out->rows = rows;
+	out->cols = b1 - b0;
+	out->nnz = nnz;
+	out->row_ptr = calloc((size_t)rows + 2, sizeof *out->row_ptr);
+	out->col_idx = malloc(sizeof *out->col_idx * (size_t)(nnz ? nnz : 1));
+	out->val = O->val ? malloc(sizeof *out->val * (size_t)(nnz ? nnz : 1)) : NULL;
+	int32_t *pos = malloc(sizeof *pos * (size_t)(nnz ? nnz : 1));
+	if (!out->row_ptr || !out->col_idx || (O->val && !out->val) || !pos) {
+		free(pos);
+		blz_csr_free(out);
+		return blz_fail(BLZ_ENOMEM, "blz_prepared_slab_short: out of memory");
+	}
+	/* padded position of every entry's output row */
+#pragma omp parallel for schedule(static) if (nnz > 200000)
+	for (int64_t k = 0; k < nnz; k++) {
+		const int64_t c = O->col_idx[k0 + k];
+		int lo = 0, hi = P->nranks - 1;		/* largest g with bounds[rs][g] <= c */
+		while (lo < hi) {
+			const int mid = (lo + hi + 1) / 2;
+			if (P->bounds[rs][mid] <= c)
+				lo = mid;
+			else
+				hi = mid - 1;
+		}
+		pos[k] = (int32_t)((int64_t)lo * P->stride[rs] + (c - P->bounds[rs][lo]));
+	}
+	for (int64_t k = 0; k < nnz; k++)
+		out->row_ptr[pos[k] + 1]++;
+	for (int64_t r = 0; r < rows; r++)
+		out->row_ptr[r + 1] += out->row_ptr[r];
+	uint32_t *fill = malloc(sizeof *fill * (size_t)(rows + 1));
+	if (!fill) {
+		free(pos);
+		blz_csr_free(out);
+		return blz_fail(BLZ_ENOMEM, "blz_prepared_slab_short: out of memory");
+	}
+	memcpy(fill, out->row_ptr, sizeof *fill * (size_t)(rows + 1));
+	for (int64_t r = b0; r < b1; r++)
+		for (uint32_t k = O->row_ptr[r]; k < O->row_ptr[r + 1]; k++) {
+			const uint32_t at = fill[pos[k - k0]]++;
+			out->col_idx[at] = (int32_t)(r - b0);
+			if (O->val)
+				out->val[at] = O->val[k];
+		}
+	free(fill);
+	free(pos);
+	return BLZ_OK;
+}
+
+int blz_prepared_describe(const blz_prepared *P, int *right, int *nranks, int *chunks)
+{
+	if (!P)
+		return blz_fail(BLZ_EINVAL, "blz_prepared_describe: NULL argument");
+	if (right)
+		*right = P->right;
+	if (nranks)
+		*nranks = P->nranks;
+	if (chunks)
+		*chunks = P->chunks;
+	return BLZ_OK;
+}
+
 static uint64_t up64(uint64_t x) { return (x + 63u) & ~(uint64_t)63u; }
 
 int blz_prepared_save(const blz_prepared *P, const char *path, uint64_t key)

@@ -205,6 +205,17 @@ class Prepared:
         lib().blz_csr_free(C.byref(A))
         return out
 
+    def slab_short(self, rank, t):
+        """blz_prepared_slab_short(): product t in its short-side form for rank `rank`."""
+        A = Csr()
+        check(lib().blz_prepared_slab_short(self.h, C.c_int(rank), C.c_int(t), C.byref(A)))
+        rp = np.ctypeslib.as_array(A.row_ptr, (A.rows + 1,)).copy()
+        ci = np.ctypeslib.as_array(A.col_idx, (max(A.nnz, 1),))[:A.nnz].copy()
+        va = np.ctypeslib.as_array(A.val, (max(A.nnz, 1),))[:A.nnz].copy() if A.val else np.ones(A.nnz, np.uint32)
+        out = dict(rows=int(A.rows), cols=int(A.cols), nnz=int(A.nnz), row_ptr=rp, col_idx=ci, val=va)
+        lib().blz_csr_free(C.byref(A))
+        return out
+
     def close(self):
         if self.h:
             lib().blz_prepared_free(self.h)
@@ -333,6 +344,9 @@ class Context:
 
     def set_matrix_prepared(self, P, rank=0):
         check(lib().blz_set_matrix_prepared(self.h, P.h, C.c_int(rank)))
+        r = C.c_int(0)
+        check(lib().blz_prepared_describe(P.h, C.byref(r), None, None))
+        self.right = bool(r.value)
 
     def rows(self, block):
         return int(lib().blz_rows(self.h, C.c_int(block)))
@@ -354,6 +368,15 @@ class Context:
         kind = C.c_int(0)
         check(lib().blz_locality(self.h, loc, C.byref(kind)))
         return (float(loc[0]), float(loc[1])), int(kind.value)
+
+    def short_side(self, transpose):
+        return bool(lib().blz_short_side(self.h, C.c_int(int(transpose))) == 1)
+
+    def get_partial(self, transpose):
+        rows = self.rows(TMP) if bool(transpose) == (not self.right) else self.rows(V)
+        out = np.zeros(rows * self.n, dtype=np.uint64)
+        check(lib().blz_get_partial(self.h, C.c_int(int(transpose)), ptr(out)))
+        return out
 
     def panel_rows(self, transpose):
         """(block rows of the operand kept in LDS, share of the entries they serve) for M*x (False) / M^T*x (True)."""
@@ -427,14 +450,14 @@ class Context:
         return float(ms.value)
 
     PROFILE_CLASSES = ("spmv1", "spmv2", "block_dot", "semi_inverse", "orthogonalize", "allgather_v",
-                       "allgather_tmp", "allreduce")
+                       "allgather_tmp", "allreduce", "reduce_scatter")
 
     def profile(self, enable):
         check(lib().blz_profile(self.h, C.c_int(int(enable))))
 
     def profile_read(self):
-        ms = (C.c_double * 8)()
-        cnt = (C.c_int64 * 8)()
+        ms = (C.c_double * len(self.PROFILE_CLASSES))()
+        cnt = (C.c_int64 * len(self.PROFILE_CLASSES))()
         check(lib().blz_profile_read(self.h, ms, cnt))
         return {k: dict(ms_total=float(ms[i]), launches=int(cnt[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
 

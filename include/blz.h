@@ -144,9 +144,17 @@ int blz_prepare(const blz_coo *M, int right, int nranks, int chunks, int reorder
 int blz_prepared_save(const blz_prepared *P, const char *path, uint64_t key);
 int blz_prepared_load(const char *path, uint64_t key, blz_prepared **out);
 void blz_prepared_free(blz_prepared *P);
+/* what P was prepared for (any pointer may be NULL) */
+int blz_prepared_describe(const blz_prepared *P, int *right, int *nranks, int *chunks);
 /* rank `rank`'s rows of M (t = 0) or of M^T (t = 1) as a CSR of its own, columns rewritten to positions in the gathered
  * operand (what blz_shard_matrix returns in slabs[t]) */
 int blz_prepared_slab(const blz_prepared *P, int rank, int t, blz_csr *slab);
+/* The matrix of product t in its SHORT-SIDE form (tall / wide matrices on several ranks): the transpose of this rank's
+ * rows of the other orientation.  Rows = the padded rank-major numbering of the output side (nranks x stride), columns =
+ * row numbers inside this rank's own slab of the operand: the rank multiplies it by its OWN slab (nothing is gathered)
+ * and a reduce-scatter of the full-length partial products replaces the all-gather of the long block
+ * (mpi/lanczos_modp.c:1108-1124 reduces partial products too, through rank 0). */
+int blz_prepared_slab_short(const blz_prepared *P, int rank, int t, blz_csr *out);
 /* 64-bit content hash of a file (0 on error) */
 uint64_t blz_file_hash(const char *path);
 
@@ -240,6 +248,15 @@ int64_t blz_panel_rows(const blz_ctx *c, int transpose, double *share);
  * rows share columns (the SpMV then walks per-XCD row ranges); *order_kind (may be NULL): 0 rows by smallest column,
  * 1 the file's order, 2 rows by the mean of their columns. */
 int blz_locality(const blz_ctx *c, double locality[2], int *order_kind);
+
+/* Short-side exchange: 1 when product `transpose` (0: M * x, 1: M^T * x) runs in its short-side form on this context
+ * -- several ranks, 64-bit words, operand side at least 8 times longer than the output side (BLZ_SHORT_SIDE=0/1
+ * overrides): the rank multiplies the transpose of its own rows of the other orientation by its own slab and a
+ * reduce-scatter of the partial products replaces the all-gather of the long block.  In external-exchange mode
+ * blz_spmv leaves the partial product on the device and blz_get_partial returns it (rows of the output side x n words,
+ * original numbering, unreduced sums) for the caller to sum over the ranks. */
+int blz_short_side(const blz_ctx *c, int transpose);
+int blz_get_partial(blz_ctx *c, int transpose, uint64_t *host);
 
 int64_t blz_rows(const blz_ctx *ctx, int block);	/* global row count of a block (N or C) */
 /* size of this rank's slab of a block; *first = its first row in the SOLVER's numbering (see blz_owner_of_row) */

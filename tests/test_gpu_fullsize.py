@@ -25,13 +25,17 @@ def addmod(a, b, p):
     return np.where(s >= p, s - np.uint64(p), s)
 
 
-@pytest.mark.parametrize("name", ["relat8", "gl7d19", "relat9"])
+@pytest.mark.parametrize("name", ["relat8", "gl7d19", "relat9", "synth5q"])
 def test_full_size_config(name):
+    """synth5q is config 5's shape at 1/4 linear scale (12.5 M x 12.5 M, 5e8 entries, all ones, n = 16): columns beyond
+    2^24 (the stream cannot be packed), 1.6 GB operands, 128-byte block rows, multi-millisecond launches."""
     w = WORKLOADS[name]
     p, n, right = w["prime"], w["n"], w["right"]
     M = blz.Matrix.synth(w["rows"], w["cols"], w["nnz"], w["seed"], p, pattern=w["pattern"])
     Mo = orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+    pair = orc.CsrPair(Mo)          # the oracle's by-rows OpenMP kernels (no per-thread copies of the output block)
     threads = min(16, os.cpu_count() or 1)
+    big = name == "synth5q"
     with blz.Context(p, n) as ctx:
         ctx.set_matrix(M, right)
         ctx.init_v()
@@ -42,11 +46,12 @@ def test_full_size_config(name):
         # one whole iteration == the oracle's (OpenMP kernels; they equal the sequential ones, test_oracle_wide.py)
         vv, tt = v0.copy(), np.zeros(max(nv, nt) * n, np.uint64)
         aa, pp = np.zeros(nv * n, np.uint64), np.zeros(nv * n, np.uint64)
-        assert orc.iteration_omp(Mo, n, p, right, vv, tt, aa, pp, threads) > 0
+        assert pair.iteration(n, p, right, vv, tt, aa, pp, threads) > 0
         done, stopped, _ = ctx.iterate(1)
         assert (done, stopped) == (1, False)
         assert np.array_equal(ctx.get_block(blz.V), vv) and np.array_equal(ctx.get_block(blz.P), pp)
         assert np.array_equal(ctx.get_block(blz.AV), aa)
+        del vv, tt, aa, pp
 
         # the reference's in-loop invariants on the n x n operands of that iteration (exact integers)
         A, B, Wi, d = (ctx.get_small(k).astype(object) for k in (blz.VTAV, blz.VTAAV, blz.WINV, blz.D))
@@ -69,9 +74,10 @@ def test_full_size_config(name):
             ctx.set_block(src, addmod(a, b, p))
             ctx.spmv(transpose, src, dst)
             assert np.array_equal(ctx.get_block(dst), addmod(ya, yb, p))
-            if transpose == (not right):
-                # and the first product against the oracle at full size
-                assert np.array_equal(ya, orc.spmv_omp(Mo, a, transpose, n, p, threads))
+            if transpose == (not right) or big:
+                # and the product against the oracle at full size (both orientations for the config-5 shape)
+                assert np.array_equal(ya, pair.spmv(a, transpose, n, p, threads))
+            del a, b, ya, yb
 
         # adjoint identity through the block products: U^T (B^T W) = (B U)^T W with B = the first product's matrix
         U = rng.integers(0, p, nv * n, dtype=np.uint64)
@@ -84,6 +90,7 @@ def test_full_size_config(name):
         BU = ctx.get_block(blz.TMP)
         rhs, _ = orc.block_dot(nt, Wb, BU, n, p, omp_threads=threads)   # (B U)^T W, summed on the host
         assert np.array_equal(lhs, rhs)
+    pair.close()
 
 
 def test_full_solve_finds_verified_kernel_vectors():

@@ -36,16 +36,29 @@ def sharded_solve(M, p, n, right, world, max_iters):
                 full += c.get_block(block)
             return full
 
+        def product(transpose, src, dst):
+            """one product of the iteration with the exchange done by hand: all-gather of the operand, or -- for a product in
+            its short-side form -- every rank multiplies its OWN slab and the partial products are summed (= reduce-scatter)"""
+            if ctxs[0].short_side(transpose):
+                assert all(c.short_side(transpose) for c in ctxs)
+                for c in ctxs:
+                    c.spmv(transpose, src, dst)
+                total = np.zeros(ctxs[0].rows(dst) * n, dtype=object)
+                for c in ctxs:
+                    total = total + c.get_partial(transpose).astype(object)
+                total = np.array(total % p, dtype=np.uint64)
+                for c in ctxs:
+                    c.set_block(dst, total)                    # each rank keeps its rows of the sum
+            else:
+                full = gather(src)
+                for c in ctxs:
+                    c.set_block(src, full)                     # = all-gather
+                    c.spmv(transpose, src, dst)
+
         its = 0
         while its < max_iters:
-            full = gather(blz.V)
-            for c in ctxs:
-                c.set_block(blz.V, full)                       # = all-gather(v)
-                c.spmv(not right, blz.V, blz.TMP)
-            full = gather(blz.TMP)
-            for c in ctxs:
-                c.set_block(blz.TMP, full)                     # = all-gather(tmp)
-                c.spmv(right, blz.TMP, blz.AV)
+            product(not right, blz.V, blz.TMP)
+            product(right, blz.TMP, blz.AV)
             parts = [c.block_dot() for c in ctxs]              # rank-local products
             a = np.zeros(n * n, dtype=object)
             b = np.zeros(n * n, dtype=object)
@@ -141,3 +154,51 @@ def test_rccl_plumbing_on_one_rank(monkeypatch, chunks):
         full = orc.block_lanczos(Mo, n, p)
         assert c.iterations == full["iterations"]
         assert np.array_equal(c.get_block(blz.V), full["v"]) and np.array_equal(c.get_block(blz.TMP), full["tmp"])
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("shape,right,forced", [((9000, 400), False, None), ((9000, 400), True, None), ((400, 9000), False, None),
+                                                ((3000, 2000), False, "1")])
+def test_short_side_exchange_with_emulated_ranks(monkeypatch, shape, right, world, forced):
+    """Tall and wide matrices on several ranks: the product whose operand lives on the long side runs in its short-side form
+    (transpose of the rank's own rows times its own slab, partial products summed over the ranks instead of an all-gather of
+    the long block); the other product keeps the all-gather of the short block.  Emulated exchange on one GPU; the trajectory
+    must be the oracle's.  BLZ_SHORT_SIDE=1 forces the form on both products of a squarish matrix."""
+    if forced:
+        monkeypatch.setenv("BLZ_SHORT_SIDE", forced)
+    p, n = P61, 8
+    M = blz.Matrix.synth(shape[0], shape[1], 12 * max(shape), 0x54414C4C, p)
+    Mo = orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+    want = orc.block_lanczos(Mo, n, p, right=right, stop_after=5)
+    probe = blz.Context(p, n)
+    probe.set_matrix(M, right, 0, world)
+    flags = (probe.short_side(False), probe.short_side(True))
+    probe.close()
+    if forced:
+        assert flags == (True, True)
+    else:
+        assert flags.count(True) == 1                         # exactly the product that would gather the long block
+    got = sharded_solve(M, p, n, right, world, 5)
+    assert got["iterations"] == want["iterations"]
+    assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["p"], want["p"])
+
+
+@pytest.mark.parametrize("shape,right", [((9000, 400), False), ((9000, 400), True), ((3000, 2000), False)])
+def test_short_side_exchange_through_rccl_on_one_rank(monkeypatch, shape, right):
+    """The real call path (ncclReduceScatter on the compute stream, then the mod-p pass) on a 1-rank communicator."""
+    monkeypatch.setenv("BLZ_FORCE_COMM", "1")
+    monkeypatch.setenv("BLZ_SHORT_SIDE", "1")
+    p, n = P61, 8
+    M = blz.Matrix.synth(shape[0], shape[1], 12 * max(shape), 0x54414C4C, p)
+    Mo = orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+    want = orc.block_lanczos(Mo, n, p, right=right, stop_after=7)
+    with blz.Context(p, n) as c:
+        c.comm_init(blz.comm_unique_id(), 0, 1)
+        c.set_matrix(M, right, 0, 1)
+        assert c.short_side(False) and c.short_side(True)
+        c.init_v()
+        c.profile(True)
+        c.iterate(7)
+        prof = c.profile_read()
+        assert prof["reduce_scatter"]["launches"] == 14 and prof["allgather_v"]["launches"] == 0
+        assert np.array_equal(c.get_block(blz.V), want["v"]) and np.array_equal(c.get_block(blz.P), want["p"])

@@ -287,3 +287,44 @@ def test_prepared_matrix_is_what_every_rank_used_to_build_and_survives_the_cache
     assert e.value.code == blz.EFORMAT
     h1 = blz.file_hash(os.path.join(GOLDEN, "rand3000x2000.mtx"))
     assert h1 == blz.file_hash(os.path.join(GOLDEN, "rand3000x2000.mtx")) != blz.file_hash(os.path.join(GOLDEN, "rand300x200.mtx"))
+
+
+@pytest.mark.parametrize("nranks,right", [(2, False), (3, True), (8, False)])
+def test_short_side_form_of_a_product_sums_to_the_gathering_form(nranks, right):
+    """blz_prepared_slab_short: rank g's matrix for the short-side form of product t is the transpose of ITS rows of the
+    other orientation, with output rows in the padded rank-major numbering; multiplied by the rank's own slab of the
+    operand and summed over the ranks it must give what the gathering form gives (exact integers here)."""
+    import scipy.sparse as sp
+    p = (1 << 61) - 1
+    M = blz.Matrix.synth(5000, 300, 20000, 0x54414C4C, p)          # tall: 5000 rows against 300 columns
+    with blz.Prepared.prepare(M, right, nranks, 1, reorder=1) as P:
+        for t in (0, 1):
+            gather = [P.slab(g, t) for g in range(nranks)]
+            short = [P.slab_short(g, t) for g in range(nranks)]
+            # sides: rows of product t live on side rs; its operand on side cs; bounds from the gathering slabs
+            rows_out = [s["rows"] for s in gather]
+            stride_out = short[0]["rows"] // nranks
+            assert all(s["rows"] == stride_out * nranks for s in short) and max(rows_out) <= stride_out
+            n_in = [s["cols"] for s in short]                       # own operand rows per rank
+            stride_in = gather[0]["cols"] // nranks
+            rng = np.random.default_rng(t)
+            xs = [rng.integers(0, 1000, size=c).astype(object) for c in n_in]
+            # gathered operand in the padded rank-major layout the gathering slabs index
+            xg = np.zeros(stride_in * nranks, dtype=object)
+            for g in range(nranks):
+                xg[g * stride_in:g * stride_in + n_in[g]] = xs[g]
+            total = np.zeros(stride_out * nranks, dtype=object)
+            for g in range(nranks):
+                S = short[g]
+                A = sp.csr_matrix((S["val"].astype(np.float64), S["col_idx"], S["row_ptr"].astype(np.int64)), shape=(S["rows"], max(S["cols"], 1)))
+                A = A.tocoo()
+                for r_, c_, v_ in zip(A.row, A.col, A.data):
+                    total[r_] += int(v_) * xs[g][c_]
+            for g in range(nranks):
+                G = gather[g]
+                want = np.zeros(G["rows"], dtype=object)
+                for r_ in range(G["rows"]):
+                    for k in range(G["row_ptr"][r_], G["row_ptr"][r_ + 1]):
+                        want[r_] += int(G["val"][k]) * xg[G["col_idx"][k]]
+                assert (total[g * stride_out:g * stride_out + G["rows"]] == want).all(), (t, g)
+                assert not total[g * stride_out + G["rows"]:(g + 1) * stride_out].any()     # padding rows stay empty
