@@ -258,6 +258,12 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 		c->cfg.staged = !(ns && ns[0] == '1');
 	}
 	{
+		const char *nm = getenv("BLZ_NO_MFMA");
+		c->cfg.mfma = !(nm && nm[0] == '1');
+		c->cfg.mfma_img = nullptr;
+		HIPCHK(hipMalloc(&c->cfg.mfma_img, ortho_mfma_image_bytes()));
+	}
+	{
 		const char *npn = getenv("BLZ_NO_PANEL");
 		c->cfg.panel = !(npn && npn[0] == '1');
 	}
@@ -334,6 +340,7 @@ extern "C" void blz_destroy(blz_ctx *c)
 		if (h) hipHostFree(h);
 	if (c->small) hipFree(c->small);
 	if (c->dot_send) hipFree(c->dot_send);
+	if (c->cfg.mfma_img) hipFree(c->cfg.mfma_img);
 	if (c->partial) hipFree(c->partial);
 	if (c->ctl) hipFree(c->ctl);
 	if (c->ev0) hipEventDestroy(c->ev0);

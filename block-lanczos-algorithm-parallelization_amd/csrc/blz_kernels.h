@@ -70,6 +70,8 @@ struct KernelCfg {
 	ModP m;
 	int num_cu;
 	int spmv_blocks_per_cu;	/* grid of the persistent SpMV = num_cu * this (BLZ_SPMV_BLOCKS_PER_CU overrides) */
+	int mfma;		/* 1: the dense row kernels use the matrix cores where they can (p = 2^61-1, n = 8 / 16); BLZ_NO_MFMA=1 */
+	void *mfma_img;		/* device scratch for the coefficient digits in MFMA fragment order (ortho_mfma_image_bytes()) */
 	int panel;		/* 1: slabs whose operand has hot block rows run k_spmv_panel; BLZ_NO_PANEL=1 turns it off */
 	int staged;		/* 1: slabs with a plan run k_spmv_staged; BLZ_NO_STAGE=1 keeps the round-1 kernels (A/B) */
 };
@@ -115,6 +117,12 @@ hipError_t launch_orthogonalize(const KernelCfg &c, void *V, const void *AV, voi
 
 /* X[i] <- X[i] mod p for 64-bit words that hold sums of a few residues (after a reduce-scatter) */
 hipError_t launch_reduce_modp(const KernelCfg &c, void *X, int64_t words, const DevCtl *ctl, hipStream_t s);
+
+/* the same update on v_mfma_i32_16x16x64_i8 (blz_dense_mfma.hip): exact integer contractions of base-256 digits */
+size_t ortho_mfma_image_bytes(void);
+bool ortho_mfma_supported(const KernelCfg &c);
+hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows, const u64 *small,
+				     const DevCtl *ctl, hipStream_t s);
 
 /* flag |= any(X != 0) over `words` words */
 hipError_t launch_any_nonzero(const KernelCfg &c, const void *X, int64_t words, int *flag, hipStream_t s);

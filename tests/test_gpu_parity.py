@@ -433,3 +433,44 @@ def test_panel_of_dense_block_rows_against_oracle(monkeypatch, n, p, kind):
                     ctx.init_v()
                     ctx.iterate(3)
                     assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
+
+
+@pytest.mark.parametrize("n", [8, 16])
+@pytest.mark.parametrize("rows", [1, 15, 16, 17, 4099, 70001])
+def test_block_update_on_the_matrix_cores_against_oracle(monkeypatch, n, rows):
+    """orthogonalize() for p = 2^61-1 at n = 8 / 16 runs on v_mfma_i32_16x16x64_i8 (exact integer contractions of the
+    base-256 digits of the block rows against signed digits of the n x n coefficients, folded mod 2^61-1): row counts
+    around the 16-row tile, several iterations so that d takes different patterns, against the oracle; BLZ_NO_MFMA=1
+    (the vector-ALU kernels) gives the same words; and one update with hand-made extreme operands (all words p-1)."""
+    p = P61
+    cols = max(rows // 2, 3)
+    rng = np.random.default_rng(rows * n)
+    nz = max(4 * rows, 8)
+    M = blz.Matrix(rows, cols, rng.integers(0, rows, nz), rng.integers(0, cols, nz),
+                   rng.choice(np.array([1, 2, 3, 2 ** 32 - 1], dtype=np.uint64), size=nz).astype(np.uint32))
+    Mo = as_orc(M)
+    want = orc.block_lanczos(Mo, n, p, stop_after=4)
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BLZ_NO_MFMA", flag)
+        with blz.Context(p, n) as ctx:
+            ctx.set_matrix(M, False)
+            ctx.init_v()
+            ctx.iterate(4)
+            assert ctx.iterations == want["iterations"]
+            assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
+        with blz.Context(p, n) as ctx:                      # (a fresh context: the solve above may have raised the stop flag)
+            ctx.set_matrix(M, False)
+            # extreme operands: every word of v, Av, p at p-1, coefficients from a semi_inverse of a dense symmetric matrix
+            big = np.full(rows * n, p - 1, dtype=np.uint64)
+            A = rng.integers(0, p, size=(n, n), dtype=np.uint64)
+            A = ((A.astype(object) + A.T.astype(object)) % p).astype(np.uint64).reshape(-1)
+            B = ((A.astype(object) * 3 + 1) % p).astype(np.uint64)
+            ctx.set_block(blz.V, big)
+            ctx.set_block(blz.AV, big)
+            ctx.set_block(blz.P, big)
+            ctx.set_small(blz.VTAV, A)
+            ctx.set_small(blz.VTAAV, B)
+            npiv, winv, d = ctx.semi_inverse()
+            ctx.orthogonalize()
+            tmp_o, p_o = orc.orthogonalize(big, big.copy(), d, A, B, winv, rows, big, n, p)
+            assert np.array_equal(ctx.get_block(blz.V), tmp_o) and np.array_equal(ctx.get_block(blz.P), p_o)
