@@ -26,6 +26,8 @@
  */
 #include "blz_kernels.h"
 
+#include <algorithm>
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 #define MBLOCK 512
@@ -294,5 +296,260 @@ hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV
 		hipLaunchKernelGGL((k_ortho_mfma<8>), dim3((unsigned)blocks), dim3(MBLOCK), OG<8>::IMG_BYTES, s, (u64 *)V, (const u64 *)AV,
 				   (u64 *)P, (long long)rows, small, img, ctl);
 	}
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------- block_dot_products on the matrix cores */
+
+/*
+ * block_dot_products(), sequential/lanczos_modp.c:443-453: vtAv = V^T Av and vtAAv = Av^T Av, two n x n sums over all
+ * block rows.  The same digit contraction as above with the ROWS as the K dimension: for digit a of the left operand and
+ * digit b of the right one, C_ab[i][j] = sum over 64 rows of (byte a of X[r,i] - 128) * (byte b of Y[r,j] - 128) is one
+ * v_mfma_i32_16x16x64_i8, accumulated by s = a + b (15 accumulators per product).  The operands need a transposition --
+ * a lane holds 16 rows of ONE column (16 coalesced 8-byte loads) and gathers byte a of each into a 16-byte fragment with
+ * a 4 x 4 byte transpose of v_perm_b32 -- and both sides are biased, which the algebra turns into COLUMN SUMS:
+ *     sum_r X[r,i] Y[r,j] = sum_s 2^(8s) sum_{a+b=s} C_ab[i][j] + 128 W (colsum_X[i] + colsum_Y[j]) - 16384 R W^2
+ * with W = sum_{a<8} 2^(8a) and R the rows processed (rows past the end count as zero rows).  The i32 accumulators start at
+ * 2^30 and are folded mod 2^61-1 into 64-bit residues every 64 tiles (4096 rows), before they can leave [2^29, 3 * 2^29].
+ * n = 16: X = V, Y = Av for vtAv and X = Y = Av for vtAAv (128 MFMAs per 64 rows).  n = 8: X = Y = [V | Av] (16 columns),
+ * one product whose off-diagonal and lower-right 8 x 8 blocks are vtAv and vtAAv (64 MFMAs per 64 rows).
+ * Output: one partial row of 2 n^2 residues per workgroup, as k_block_dot_fast writes them (k_dot_finalize sums them).
+ */
+#define DBLOCK 256
+
+/* fragments of the 8 base-256 digits of 16 words: digit a of word q goes to byte q of frag[a] (4 dwords), biased by 128 */
+MODP_DEV void digit_fragments(const u64 *x, v4i *frag)
+{
+#pragma unroll
+	for (int d = 0; d < 4; d++) {
+#pragma unroll
+		for (int half = 0; half < 2; half++) {
+			u32 w0 = (u32)(x[4 * d + 0] >> (32 * half)), w1 = (u32)(x[4 * d + 1] >> (32 * half));
+			u32 w2 = (u32)(x[4 * d + 2] >> (32 * half)), w3 = (u32)(x[4 * d + 3] >> (32 * half));
+			/* 4 x 4 byte transpose: t = bytes {w0.b0 w1.b0 w0.b1 w1.b1} ..., then pairs of 16-bit halves */
+			const u32 t01l = __builtin_amdgcn_perm(w1, w0, 0x05010400u);	/* w0.b0 w1.b0 w0.b1 w1.b1 */
+			const u32 t01h = __builtin_amdgcn_perm(w1, w0, 0x07030602u);	/* w0.b2 w1.b2 w0.b3 w1.b3 */
+			const u32 t23l = __builtin_amdgcn_perm(w3, w2, 0x05010400u);
+			const u32 t23h = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+			const u32 a0 = __builtin_amdgcn_perm(t23l, t01l, 0x05040100u);	/* digit 4*half + 0 of words 4d..4d+3 */
+			const u32 a1 = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
+			const u32 a2 = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
+			const u32 a3 = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
+			frag[4 * half + 0][d] = (int)(a0 ^ 0x80808080u);
+			frag[4 * half + 1][d] = (int)(a1 ^ 0x80808080u);
+			frag[4 * half + 2][d] = (int)(a2 ^ 0x80808080u);
+			frag[4 * half + 3][d] = (int)(a3 ^ 0x80808080u);
+		}
+	}
+}
+
+MODP_DEV u64 shfl64m(u64 x, int src)
+{
+	const u32 lo = (u32)__shfl((int)(u32)x, src, 64), hi = (u32)__shfl((int)(u32)(x >> 32), src, 64);
+	return ((u64)hi << 32) | lo;
+}
+
+MODP_DEV u64 fold_partial61(u64 s)	/* s < 2^64 -> < 2^62, congruent mod 2^61 - 1 */
+{
+	return (s & ((1ull << 61) - 1)) + (s >> 61);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(DBLOCK)
+k_block_dot_mfma(const u64 *__restrict__ V, const u64 *__restrict__ AV, long long rows, u64 *__restrict__ partial,
+		 const DevCtl *__restrict__ ctl)
+{
+	if (ctl->stop)
+		return;
+	constexpr int NP = NT == 16 ? 2 : 1, WAVES = DBLOCK / 64, NN = NT * NT;
+	const u64 PR = (1ull << 61) - 1;
+	__shared__ u64 red[WAVES][NP][4][64];
+	__shared__ u64 csum[WAVES][2][64];
+	u32 one;
+	asm volatile("s_mov_b32 %0, 1" : "=s"(one));
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, h = lane >> 4;
+	const long long wave = (long long)blockIdx.x * WAVES + wv, nwaves = (long long)gridDim.x * WAVES;
+	const long long ntiles = (rows + 63) >> 6;
+	v4i acc[NP][15];
+	u64 res[NP][4];
+#pragma unroll
+	for (int p_ = 0; p_ < NP; p_++) {
+#pragma unroll
+		for (int s = 0; s < 15; s++)
+			acc[p_][s] = (v4i){ 1 << 30, 1 << 30, 1 << 30, 1 << 30 };
+#pragma unroll
+		for (int reg = 0; reg < 4; reg++)
+			res[p_][reg] = 0;
+	}
+	u64 cs0 = 0, cs1 = 0;		/* column sums (mod p, lazily folded) of this lane's column of V-side / Av-side operand */
+	long long nflush = 0, ntl = 0;
+	int pending = 0;
+	auto flush = [&]() {
+#pragma unroll
+		for (int p_ = 0; p_ < NP; p_++) {
+#pragma unroll
+			for (int reg = 0; reg < 4; reg++) {
+				u64 L = 0, H = 0;
+#pragma unroll
+				for (int s = 0; s < 15; s++) {
+					const int sh = fold_shift(s);
+					const u32 mul = one << (sh < 32 ? sh : sh - 32);
+					if (sh < 32)
+						mad_u64(L, (u32)acc[p_][s][reg], mul);
+					else
+						mad_u64(H, (u32)acc[p_][s][reg], mul);
+				}
+				/* L < 8 * 2^31 * 2^27 = 2^61, H likewise < 2^61: fold H first so that fold61's bounds hold */
+				const u64 x = fold61(L, 0), y = fold61(H, 0);
+				/* y * 2^32 mod p */
+				const unsigned __int128 t = (unsigned __int128)y << 32;
+				u64 z = ((u64)t & PR) + (u64)(t >> 61);
+				z = (z & PR) + (z >> 61);
+				z = z >= PR ? z - PR : z;
+				res[p_][reg] = addmod(res[p_][reg], addmod(x, z, PR), PR);
+			}
+#pragma unroll
+			for (int s = 0; s < 15; s++)
+				acc[p_][s] = (v4i){ 1 << 30, 1 << 30, 1 << 30, 1 << 30 };
+		}
+		nflush++;
+		pending = 0;
+	};
+	for (long long tile = wave; tile < ntiles; tile += nwaves) {
+		const long long r0 = (tile << 6) + 16 * h;
+		u64 xv[16], xa[16];
+#pragma unroll
+		for (int q = 0; q < 16; q++) {
+			const long long r = r0 + q;
+			if (NT == 16) {
+				xv[q] = r < rows ? V[(size_t)r * 16 + m] : 0;
+				xa[q] = r < rows ? AV[(size_t)r * 16 + m] : 0;
+			} else {
+				const u64 *src = m < 8 ? V : AV;
+				xv[q] = r < rows ? src[(size_t)r * 8 + (m & 7)] : 0;
+			}
+		}
+		/* column sums, folded every four additions (values < 2^61) */
+#pragma unroll
+		for (int q = 0; q < 16; q += 4) {
+			cs0 = fold_partial61(cs0 + xv[q] + xv[q + 1] + xv[q + 2] + xv[q + 3]);
+			if (NT == 16)
+				cs1 = fold_partial61(cs1 + xa[q] + xa[q + 1] + xa[q + 2] + xa[q + 3]);
+		}
+		v4i fv[8], fa[8];
+		digit_fragments(xv, fv);
+		if (NT == 16)
+			digit_fragments(xa, fa);
+#pragma unroll
+		for (int a = 0; a < 8; a++) {
+#pragma unroll
+			for (int b = 0; b < 8; b++) {
+				if (NT == 16) {
+					acc[0][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv[a], fa[b], acc[0][a + b], 0, 0, 0);
+					acc[NP - 1][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fa[b], acc[NP - 1][a + b], 0, 0, 0);
+				} else {
+					acc[0][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv[a], fv[b], acc[0][a + b], 0, 0, 0);
+				}
+			}
+		}
+		ntl++;
+		if (++pending == 64)
+			flush();
+	}
+	if (pending)
+		flush();
+	/* the 2^30 every accumulator started from, per flush: nflush * 2^30 * sum_s 2^(8 s mod 61) */
+	u64 biasw = 0;
+	for (int s = 0; s < 15; s++) {
+		const unsigned __int128 t = (unsigned __int128)(1u << 30) << fold_shift(s);
+		biasw = addmod(biasw, (u64)(t % PR), PR);
+	}
+	const u64 nfl = (u64)(nflush % (long long)PR);
+	const u64 bias_total = mulmod<61>(biasw, nfl, ModP{ PR, 0, 61, 32 });
+	/* per wave: residues in the accumulator layout (row i = 4 h + reg, column j = lane & 15) and the column sums */
+#pragma unroll
+	for (int p_ = 0; p_ < NP; p_++)
+#pragma unroll
+		for (int reg = 0; reg < 4; reg++)
+			red[wv][p_][reg][lane] = addmod(res[p_][reg], bias_total ? PR - bias_total : 0, PR);
+	{
+		u64 c0 = fold61(cs0, 0), c1 = fold61(cs1, 0);
+		csum[wv][0][lane] = c0;
+		csum[wv][1][lane] = c1;
+	}
+	__shared__ long long tiles_sh[WAVES];
+	if (lane == 0)
+		tiles_sh[wv] = ntl;
+	__syncthreads();
+	if (wv != 0)
+		return;
+	/* wavefront 0: sum over the wavefronts, add the bias terms, write the partial row */
+	long long tl = 0;
+	for (int w = 0; w < WAVES; w++)
+		tl += tiles_sh[w];
+	const ModP mp = { PR, 0, 61, 32 };
+	/* W = sum_{a<8} 2^(8a) mod p, K1 = 128 W, K2 = 16384 W^2, R = 64 rows per tile */
+	u64 W = 0;
+	for (int a = 0; a < 8; a++) {
+		const unsigned __int128 t = (unsigned __int128)1 << (8 * a);
+		W = addmod(W, (u64)(t % PR), PR);
+	}
+	const u64 K1 = mulmod<61>(W, 128, mp), K2 = mulmod<61>(mulmod<61>(W, W, mp), 16384, mp);
+	const u64 Rm = (u64)((tl * 64) % (long long)PR);
+	const u64 k2r = mulmod<61>(K2, Rm, mp);
+	/* column sums over the 4 k-blocks (lanes m, m+16, m+32, m+48) and the wavefronts */
+	u64 col0 = 0, col1 = 0;		/* of column (lane & 15) */
+	for (int w = 0; w < WAVES; w++)
+		for (int hh = 0; hh < 4; hh++) {
+			col0 = addmod(col0, csum[w][0][m + 16 * hh], PR);
+			col1 = addmod(col1, csum[w][1][m + 16 * hh], PR);
+		}
+	u64 *out = partial + (size_t)blockIdx.x * 2 * NN;
+#pragma unroll
+	for (int p_ = 0; p_ < NP; p_++) {
+#pragma unroll
+		for (int reg = 0; reg < 4; reg++) {
+			const int i = 4 * h + reg, j = m;
+			u64 x = 0;
+			for (int w = 0; w < WAVES; w++)
+				x = addmod(x, red[w][p_][reg][lane], PR);
+			/* operand sides: n = 16: product 0 = V^T Av (X = V-side sums, Y = Av-side), product 1 = Av^T Av; n = 8: X = Y = [V | Av] */
+			/* lane i (h = 0, m = i) holds the sums of column i: the row index of this output needs them from there */
+			const u64 r0c = shfl64m(col0, i), r1c = shfl64m(col1, i);
+			const u64 sx = NT == 16 ? (p_ == 0 ? r0c : r1c) : r0c;
+			const u64 sy = NT == 16 ? col1 : col0;
+			x = addmod(x, mulmod<61>(K1, addmod(sx, sy, PR), mp), PR);
+			x = addmod(x, k2r ? PR - k2r : 0, PR);
+			if (NT == 16) {
+				out[p_ * NN + i * 16 + j] = x;
+			} else {
+				if (i < 8 && j >= 8)
+					out[i * 8 + (j - 8)] = x;		/* v^T Av */
+				else if (i >= 8 && j >= 8)
+					out[NN + (i - 8) * 8 + (j - 8)] = x;	/* Av^T Av */
+			}
+		}
+	}
+}
+
+bool block_dot_mfma_supported(const KernelCfg &c)
+{
+	return c.mfma && c.word == 8 && c.mers == 61 && (c.n == 8 || c.n == 16);
+}
+
+hipError_t launch_block_dot_mfma(const KernelCfg &c, const void *V, const void *AV, int64_t rows, u64 *partial, int max_blocks,
+				 int *nblocks, const DevCtl *ctl, hipStream_t s)
+{
+	const long long ntiles = (rows + 63) / 64;
+	long long blocks = (ntiles + DBLOCK / 64 - 1) / (DBLOCK / 64);
+	const long long cap = std::min<long long>(max_blocks, (long long)c.num_cu * (c.n == 16 ? 1 : 2));
+	blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+	*nblocks = (int)blocks;
+	if (c.n == 16)
+		hipLaunchKernelGGL((k_block_dot_mfma<16>), dim3((unsigned)blocks), dim3(DBLOCK), 0, s, (const u64 *)V, (const u64 *)AV,
+				   (long long)rows, partial, ctl);
+	else
+		hipLaunchKernelGGL((k_block_dot_mfma<8>), dim3((unsigned)blocks), dim3(DBLOCK), 0, s, (const u64 *)V, (const u64 *)AV,
+				   (long long)rows, partial, ctl);
 	return hipGetLastError();
 }

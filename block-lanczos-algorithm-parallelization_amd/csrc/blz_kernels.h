@@ -124,6 +124,11 @@ bool ortho_mfma_supported(const KernelCfg &c);
 hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows, const u64 *small,
 				     const DevCtl *ctl, hipStream_t s);
 
+/* block_dot_products on the matrix cores (p = 2^61-1, n = 8 / 16): same partial rows as launch_block_dot */
+bool block_dot_mfma_supported(const KernelCfg &c);
+hipError_t launch_block_dot_mfma(const KernelCfg &c, const void *V, const void *AV, int64_t rows, u64 *partial, int max_blocks,
+				 int *nblocks, const DevCtl *ctl, hipStream_t s);
+
 /* flag |= any(X != 0) over `words` words */
 hipError_t launch_any_nonzero(const KernelCfg &c, const void *X, int64_t words, int *flag, hipStream_t s);
 

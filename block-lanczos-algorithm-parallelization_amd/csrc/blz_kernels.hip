@@ -1551,6 +1551,8 @@ static hipError_t dot_dispatch(const KernelCfg &c, const W *V, const W *AV, int6
 hipError_t launch_block_dot(const KernelCfg &c, const void *V, const void *AV, int64_t rows, u64 *partial,
 			    int max_blocks, int *nblocks, const DevCtl *ctl, hipStream_t s)
 {
+	if (block_dot_mfma_supported(c) && rows >= 4096)	/* below that one VALU workgroup is quicker than the fold set-up */
+		return launch_block_dot_mfma(c, V, AV, rows, partial, max_blocks, nblocks, ctl, s);
 	if (c.word == 4)
 		return c.mers == 31 ? dot_dispatch<u32, 31>(c, (const u32 *)V, (const u32 *)AV, rows, partial, max_blocks, nblocks, ctl, s)
 				    : dot_dispatch<u32, 0>(c, (const u32 *)V, (const u32 *)AV, rows, partial, max_blocks, nblocks, ctl, s);

@@ -474,3 +474,31 @@ def test_block_update_on_the_matrix_cores_against_oracle(monkeypatch, n, rows):
             ctx.orthogonalize()
             tmp_o, p_o = orc.orthogonalize(big, big.copy(), d, A, B, winv, rows, big, n, p)
             assert np.array_equal(ctx.get_block(blz.V), tmp_o) and np.array_equal(ctx.get_block(blz.P), p_o)
+
+
+@pytest.mark.parametrize("n", [8, 16])
+@pytest.mark.parametrize("rows", [4096, 4097, 70001, 600000])
+def test_inner_products_on_the_matrix_cores_against_oracle(monkeypatch, n, rows):
+    """block_dot_products for p = 2^61-1 at n = 8 / 16 on v_mfma_i32_16x16x64_i8 (rows as the K dimension, both operands
+    biased, the bias terms turned into column sums, i32 accumulators folded mod p every 64 tiles): random blocks and the
+    extreme block (all words p-1), row counts around the 64-row tile and past the first fold, against the oracle;
+    BLZ_NO_MFMA=1 gives the same words."""
+    p = P61
+    rng = np.random.default_rng(rows + n)
+    M = blz.Matrix(rows, 8, rng.integers(0, rows, 64), rng.integers(0, 8, 64), np.ones(64, dtype=np.uint32))
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BLZ_NO_MFMA", flag)
+        with blz.Context(p, n) as ctx:
+            ctx.set_matrix(M, False)
+            for kind in ("random", "max"):
+                if kind == "random":
+                    v = rng.integers(0, p, rows * n, dtype=np.uint64)
+                    a = rng.integers(0, p, rows * n, dtype=np.uint64)
+                else:
+                    v = np.full(rows * n, p - 1, dtype=np.uint64)
+                    a = np.full(rows * n, p - 1, dtype=np.uint64)
+                ctx.set_block(blz.V, v)
+                ctx.set_block(blz.AV, a)
+                got = ctx.block_dot()
+                want = orc.block_dot(rows, a, v, n, p, omp_threads=8)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (kind, flag)
