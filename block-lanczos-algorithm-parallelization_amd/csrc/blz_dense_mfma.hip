@@ -283,10 +283,14 @@ hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV
 	blocks = blocks > cap ? cap : blocks;
 	unsigned char *img = (unsigned char *)c.mfma_img;
 	if (c.n == 16) {
-		static bool attr = false;
-		if (!attr) {
+		/* more than 64 KB of dynamic LDS needs the attribute, once per DEVICE (several contexts of one process) */
+		static bool attr[64] = { false };
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		if (dev < 0 || dev >= 64 || !attr[dev]) {
 			(void)hipFuncSetAttribute((const void *)k_ortho_mfma<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OG<16>::IMG_BYTES);
-			attr = true;
+			if (dev >= 0 && dev < 64)
+				attr[dev] = true;
 		}
 		hipLaunchKernelGGL((k_ortho_mfma_prep<16>), dim3(32), dim3(256), 0, s, small, img, c.m.p, ctl);
 		hipLaunchKernelGGL((k_ortho_mfma<16>), dim3((unsigned)blocks), dim3(MBLOCK), OG<16>::IMG_BYTES, s, (u64 *)V, (const u64 *)AV,

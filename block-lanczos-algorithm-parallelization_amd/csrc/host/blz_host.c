@@ -830,79 +830,74 @@ static int cmp_i32(const void *a, const void *b)
 	return x < y ? -1 : x > y;
 }
 
-/* entries grouped by idx: start[count + 1], order[nnz] */
-static int group_entries(const int32_t *idx, int64_t count, int64_t nnz, int64_t **start_out, int32_t **order_out)
-{
-	int64_t *start = calloc((size_t)count + 2, sizeof *start);
-	int32_t *order = malloc(sizeof *order * (size_t)(nnz ? nnz : 1));
-	if (!start || !order) {
-		free(start);
-		free(order);
-		return blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
-	}
-	for (int64_t k = 0; k < nnz; k++)
-		start[idx[k] + 1]++;
-	for (int64_t q = 0; q < count; q++)
-		start[q + 1] += start[q];
-	int64_t *fill = malloc(sizeof *fill * (size_t)(count + 1));
-	if (!fill) {
-		free(start);
-		free(order);
-		return blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
-	}
-	memcpy(fill, start, sizeof *fill * (size_t)(count + 1));
-	for (int64_t k = 0; k < nnz; k++)
-		order[fill[idx[k]]++] = (int32_t)k;
-	free(fill);
-	*start_out = start;
-	*order_out = order;
-	return BLZ_OK;
-}
-
-/* lines touched / entries, summed over sampled windows of the product whose rows are `own` and operand rows `other` */
-static void score_product(int64_t n_own, const int32_t *perm_own, const int32_t *other_idx, const int32_t *perm_other,
-			  const int64_t *start, const int32_t *order, int line_shift, int64_t win, int samples,
+/* lines touched / entries, summed over `samples` windows of `win` consecutive (new) rows of the product whose rows are
+ * `own` and whose operand rows are `other`.  Two parallel passes over the entries (count, fill) collect the operand lines
+ * of the sampled windows; each window is then sorted and its distinct lines counted.  No index of the whole matrix is built. */
+static void score_product(int64_t n_own, const int32_t *own_idx, const int32_t *perm_own, const int32_t *other_idx,
+			  const int32_t *perm_other, int64_t nnz, int line_shift, int64_t win, int samples,
 			  const unsigned char *skip_other, double *lines_out, double *entries_out)
 {
-	int32_t *inv = malloc(sizeof *inv * (size_t)(n_own ? n_own : 1));
-	double lines = 0.0, entries = 0.0;
-	if (inv) {
-		for (int64_t r = 0; r < n_own; r++)
-			inv[perm_own[r]] = (int32_t)r;
-		if (win > n_own)
-			win = n_own;
-		const int64_t nwin = n_own / win > 0 ? n_own / win : 1;
-		if (samples > nwin)
-			samples = (int)nwin;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : lines, entries)
-		for (int sidx = 0; sidx < samples; sidx++) {
-			const int64_t w0 = (nwin * sidx / samples) * win;
-			int64_t cnt = 0;
-			for (int64_t q = w0; q < w0 + win && q < n_own; q++)
-				cnt += start[inv[q] + 1] - start[inv[q]];
-			int32_t *buf = malloc(sizeof *buf * (size_t)(cnt ? cnt : 1));
-			if (!buf)
-				continue;
-			int64_t at = 0;
-			for (int64_t q = w0; q < w0 + win && q < n_own; q++)
-				for (int64_t k = start[inv[q]]; k < start[inv[q] + 1]; k++) {
-					const int32_t o = other_idx[order[k]];
-					if (skip_other && skip_other[o])	/* panel rows are not gathered */
-						continue;
-					buf[at++] = perm_other[o] >> line_shift;
-				}
-			qsort(buf, (size_t)at, sizeof *buf, cmp_i32);
-			int64_t distinct = 0;
-			for (int64_t k = 0; k < at; k++)
-				distinct += (k == 0 || buf[k] != buf[k - 1]);
-			lines += (double)distinct;
-			entries += (double)at;
-			free(buf);
-		}
-		free(inv);
+	*lines_out = 0.0;
+	*entries_out = 0.0;
+	if (n_own <= 0 || nnz <= 0)
+		return;
+	if (win > n_own)
+		win = n_own;
+	const int64_t nwin = (n_own + win - 1) / win;
+	if (samples > nwin)
+		samples = (int)nwin;
+	int32_t *slot = malloc(sizeof *slot * (size_t)nwin);
+	int64_t *cnt = calloc((size_t)samples + 1, sizeof *cnt), *pos = calloc((size_t)samples + 1, sizeof *pos);
+	if (!slot || !cnt || !pos) {
+		free(slot);
+		free(cnt);
+		free(pos);
+		return;
 	}
-	*lines_out = lines;
-	*entries_out = entries;
+	for (int64_t w = 0; w < nwin; w++)
+		slot[w] = -1;
+	for (int sidx = 0; sidx < samples; sidx++)
+		slot[nwin * sidx / samples] = sidx;
+#pragma omp parallel for schedule(static) if (nnz > 200000)
+	for (int64_t k = 0; k < nnz; k++) {
+		const int sl = slot[perm_own[own_idx[k]] / win];
+		if (sl >= 0 && !(skip_other && skip_other[other_idx[k]])) {
+#pragma omp atomic
+			cnt[sl + 1]++;
+		}
+	}
+	for (int sidx = 0; sidx < samples; sidx++)
+		cnt[sidx + 1] += cnt[sidx];
+	int32_t *buf = malloc(sizeof *buf * (size_t)(cnt[samples] ? cnt[samples] : 1));
+	if (buf) {
+#pragma omp parallel for schedule(static) if (nnz > 200000)
+		for (int64_t k = 0; k < nnz; k++) {
+			const int sl = slot[perm_own[own_idx[k]] / win];
+			if (sl >= 0 && !(skip_other && skip_other[other_idx[k]])) {
+				int64_t at;
+#pragma omp atomic capture
+				at = pos[sl]++;
+				buf[cnt[sl] + at] = perm_other[other_idx[k]] >> line_shift;
+			}
+		}
+		double lines = 0.0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : lines)
+		for (int sidx = 0; sidx < samples; sidx++) {
+			int32_t *b = buf + cnt[sidx];
+			const int64_t m = cnt[sidx + 1] - cnt[sidx];
+			qsort(b, (size_t)m, sizeof *b, cmp_i32);
+			int64_t distinct = 0;
+			for (int64_t k = 0; k < m; k++)
+				distinct += (k == 0 || b[k] != b[k - 1]);
+			lines += (double)distinct;
+		}
+		*lines_out = lines;
+		*entries_out = (double)cnt[samples];
+		free(buf);
+	}
+	free(slot);
+	free(cnt);
+	free(pos);
 }
 
 /* positions of the non-hot items in key order behind the hot ones (list[0..nhot) by descending degree) */
@@ -957,9 +952,12 @@ static int make_order(const blz_coo *M, int kind, unsigned char *const is_hot[2]
 		} else {
 			memset(sum, 0, sizeof *sum * (size_t)M->nrows);
 			memset(cnt, 0, sizeof *cnt * (size_t)M->nrows);
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
 			for (int64_t k = 0; k < M->nnz; k++)
 				if (!is_hot[1][M->j[k]]) {
+#pragma omp atomic
 					sum[M->i[k]] += (double)M->j[k];
+#pragma omp atomic
 					cnt[M->i[k]]++;
 				}
 			for (int64_t r = 0; r < M->nrows; r++)
@@ -983,9 +981,12 @@ static int make_order(const blz_coo *M, int kind, unsigned char *const is_hot[2]
 		} else {
 			memset(sum, 0, sizeof *sum * (size_t)M->ncols);
 			memset(cnt, 0, sizeof *cnt * (size_t)M->ncols);
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
 			for (int64_t k = 0; k < M->nnz; k++)
 				if (!is_hot[0][M->i[k]]) {
+#pragma omp atomic
 					sum[M->j[k]] += (double)row_perm[M->i[k]];
+#pragma omp atomic
 					cnt[M->j[k]]++;
 				}
 			for (int64_t c = 0; c < M->ncols; c++)
@@ -1018,19 +1019,25 @@ int blz_reorder_auto(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int
 	int32_t *deg = calloc((size_t)big + 1, sizeof *deg);
 	int32_t *list[2] = { NULL, NULL };
 	unsigned char *is_hot[2] = { calloc((size_t)N[0] + 1, 1), calloc((size_t)N[1] + 1, 1) };
-	int64_t *start[2] = { NULL, NULL };
-	int32_t *order[2] = { NULL, NULL };
 	int32_t *cand_r = malloc(sizeof *cand_r * (size_t)(N[0] ? N[0] : 1)), *cand_c = malloc(sizeof *cand_c * (size_t)(N[1] ? N[1] : 1));
 	int rc = (deg && is_hot[0] && is_hot[1] && cand_r && cand_c) ? BLZ_OK : blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
 	for (int sd = 0; sd < 2 && rc == BLZ_OK; sd++) {
-		const int32_t *idx = sd == 0 ? M->i : M->j;
-		memset(deg, 0, sizeof *deg * (size_t)(N[sd] + 1));
-		for (int64_t k = 0; k < M->nnz; k++)
-			deg[idx[k]]++;
 		list[sd] = malloc(sizeof(int32_t) * (size_t)(hot[sd] > 0 ? hot[sd] : 1));
 		if (!list[sd]) {
 			rc = blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
 			break;
+		}
+		share[sd] = 0.0;
+		if (hot[sd] <= 0) {		/* no panel asked for (several ranks): no degrees needed */
+			hot[sd] = 0;
+			continue;
+		}
+		const int32_t *idx = sd == 0 ? M->i : M->j;
+		memset(deg, 0, sizeof *deg * (size_t)(N[sd] + 1));
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
+		for (int64_t k = 0; k < M->nnz; k++) {
+#pragma omp atomic
+			deg[idx[k]]++;
 		}
 		int64_t held = 0;
 		int64_t got = pick_hot(deg, N[sd], hot[sd], list[sd], &held);
@@ -1040,17 +1047,21 @@ int blz_reorder_auto(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int
 		hot[sd] = got;
 		for (int64_t a = 0; a < got; a++)
 			is_hot[sd][list[sd][a]] = 1;
-		rc = group_entries(idx, N[sd], M->nnz, &start[sd], &order[sd]);
 	}
-	double best = -1.0;
+	/* round 1's order and the file's own are always compared; the mean order only when the file's order already beats
+	 * round 1's by 10 % (there is structure to tidy) and the matrix is not huge (each candidate is two passes over it) */
+	double best = -1.0, score[ORD_KINDS] = { -1.0, -1.0, -1.0 };
 	for (int kind = 0; kind < ORD_KINDS && rc == BLZ_OK; kind++) {
+		if (kind == ORD_BARYCENTRE && !(score[ORD_IDENTITY] < 0.9 * score[ORD_SMALLEST] && M->nnz < 500000000))
+			continue;
 		if ((rc = make_order(M, kind, is_hot, list, hot, cand_r, cand_c)) != BLZ_OK)
 			break;
 		double ln[2], en[2];
 		/* product 0: rows of M gather block rows by column; product 1: rows of M^T (columns of M) gather by row */
-		score_product(N[0], cand_r, M->j, cand_c, start[0], order[0], line_shift, 4096, 48, is_hot[1], &ln[0], &en[0]);
-		score_product(N[1], cand_c, M->i, cand_r, start[1], order[1], line_shift, 4096, 48, is_hot[0], &ln[1], &en[1]);
+		score_product(N[0], M->i, cand_r, M->j, cand_c, M->nnz, line_shift, 4096, 32, is_hot[1], &ln[0], &en[0]);
+		score_product(N[1], M->j, cand_c, M->i, cand_r, M->nnz, line_shift, 4096, 32, is_hot[0], &ln[1], &en[1]);
 		const double tot = ln[0] + ln[1];
+		score[kind] = tot;
 		if (best < 0.0 || tot < best * 0.995) {	/* a later candidate must win by more than the sampling noise */
 			best = tot;
 			memcpy(row_perm, cand_r, sizeof *cand_r * (size_t)N[0]);
@@ -1067,8 +1078,6 @@ int blz_reorder_auto(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int
 	for (int sd = 0; sd < 2; sd++) {
 		free(list[sd]);
 		free(is_hot[sd]);
-		free(start[sd]);
-		free(order[sd]);
 	}
 	return rc;
 }

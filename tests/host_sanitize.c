@@ -51,6 +51,67 @@ static void matrix_round(const blz_coo *M, uint64_t prime, const char *scratch)
 						blz_csr_free(&slabs[s]);
 					}
 				}
+	/* round 2: scored renumbering with and without a hot panel, row sort, the prepared matrix (every rank's slabs in
+	 * both forms), its cache file (save, map, wrong key, truncated), the file hash */
+	{
+		int32_t *r2 = malloc(sizeof *r2 * (size_t)(M->nrows + 1)), *c2 = malloc(sizeof *c2 * (size_t)(M->ncols + 1));
+		REQUIRE(r2 && c2);
+		int64_t hot[2] = { 7, 300 };
+		double share[2], loc[2];
+		int kind = -1;
+		REQUIRE(blz_reorder_hot(M, r2, c2, hot, 0.0, share) == BLZ_OK);
+		REQUIRE(hot[0] <= 7 && hot[1] <= 300);
+		hot[0] = 5;
+		hot[1] = 64;
+		REQUIRE(blz_reorder_auto(M, r2, c2, hot, 0.01, share, 2, loc, &kind) == BLZ_OK && kind >= 0 && kind <= 2);
+		for (int64_t r = 0; r < M->nrows; r++)
+			REQUIRE(r2[r] >= 0 && r2[r] < M->nrows);
+		free(r2);
+		free(c2);
+		blz_csr A;
+		REQUIRE(blz_csr_from_coo(M, 1, 0, &A) == BLZ_OK);
+		blz_csr_sort_rows(&A);
+		for (int64_t r = 0; r < A.rows; r++)
+			for (uint32_t k = A.row_ptr[r] + 1; k < A.row_ptr[r + 1]; k++)
+				REQUIRE(A.col_idx[k - 1] <= A.col_idx[k]);
+		blz_csr_free(&A);
+	}
+	for (int right = 0; right < 2; right++)
+		for (int nranks = 1; nranks <= 4; nranks += 3) {
+			const int chunks = nranks == 1 ? 1 : 2;
+			blz_prepared *P = NULL, *Q = NULL;
+			REQUIRE(blz_prepare(M, right, nranks, chunks, 1, 2, nranks == 1 ? 50 : 0, 0.05, &P) == BLZ_OK);
+			int pr, pn, pc;
+			REQUIRE(blz_prepared_describe(P, &pr, &pn, &pc) == BLZ_OK && pr == right && pn == nranks && pc == chunks);
+			char cpath[1024];
+			snprintf(cpath, sizeof cpath, "%s/prep.blzcache", scratch);
+			REQUIRE(blz_prepared_save(P, cpath, 77 + (uint64_t)nranks) == BLZ_OK);
+			REQUIRE(blz_prepared_load(cpath, 78 + (uint64_t)nranks, &Q) != BLZ_OK && Q == NULL);
+			REQUIRE(blz_prepared_load(cpath, 77 + (uint64_t)nranks, &Q) == BLZ_OK);
+			for (int rank = 0; rank < nranks; rank++)
+				for (int t = 0; t < 2; t++) {
+					blz_csr a, b, sh;
+					REQUIRE(blz_prepared_slab(P, rank, t, &a) == BLZ_OK && blz_prepared_slab(Q, rank, t, &b) == BLZ_OK);
+					REQUIRE(a.rows == b.rows && a.nnz == b.nnz);
+					REQUIRE(!memcmp(a.row_ptr, b.row_ptr, sizeof *a.row_ptr * (size_t)(a.rows + 1)));
+					REQUIRE(!memcmp(a.col_idx, b.col_idx, sizeof *a.col_idx * (size_t)a.nnz));
+					REQUIRE(blz_prepared_slab_short(Q, rank, t, &sh) == BLZ_OK);
+					for (int64_t k = 0; k < sh.nnz; k++)
+						REQUIRE(sh.col_idx[k] >= 0 && sh.col_idx[k] < (sh.cols > 0 ? sh.cols : 1));
+					REQUIRE(sh.row_ptr[sh.rows] == (uint32_t)sh.nnz);
+					blz_csr_free(&a);
+					blz_csr_free(&b);
+					blz_csr_free(&sh);
+				}
+			blz_prepared_free(Q);
+			blz_prepared_free(P);
+			FILE *fc = fopen(cpath, "r+");
+			REQUIRE(fc && ftruncate(fileno(fc), 100) == 0);
+			fclose(fc);
+			Q = NULL;
+			REQUIRE(blz_prepared_load(cpath, 77 + (uint64_t)nranks, &Q) != BLZ_OK);
+			REQUIRE(blz_file_hash(cpath) != 0 && blz_file_hash("/nonexistent-file") == 0);
+		}
 	char path[1024];
 	snprintf(path, sizeof path, "%s/copy.mtx", scratch);
 	REQUIRE(blz_mm_save_coo(path, M) == BLZ_OK);
@@ -87,6 +148,10 @@ int main(int argc, char **argv)
 	matrix_round(&P, primes[2], scratch);
 	blz_coo_free(&P);
 	REQUIRE(blz_synth_coo(10, 3, 40, 1, 0, 7, &P) != BLZ_OK);		/* more entries per row than columns */
+	REQUIRE(blz_synth_structured(40000, 42000, 400000, 3, 0, primes[2], 40, 30, 512, &P) == BLZ_OK);
+	matrix_round(&P, primes[2], scratch);
+	blz_coo_free(&P);
+	REQUIRE(blz_synth_structured(100, 100, 400, 3, 0, 7, 60, 60, 64, &P) != BLZ_OK);	/* percentages above 100 */
 
 	/* RNG, kernel writer, checker (zero block, wrong block, bad shapes), both word widths */
 	const int n = 4;
