@@ -13,6 +13,7 @@
  *   small  = [vtAv | vtAAv | winv | d | c | vtAvd], 6*n*n words;  ctl = DevCtl.
  */
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <cmath>
@@ -122,6 +123,7 @@ struct blz_ctx {
 	int max_dot_blocks = 0;
 	DevCtl *ctl = nullptr;
 	DevCtl host_ctl{};
+	DevCtl *ctl_pinned = nullptr, *ctl_pinned_dev = nullptr;	/* host-mapped landing place of the control words */
 	ncclComm_t comm = nullptr;
 	/* perm[side][original row] = row in the solver's numbering (empty = identity); inv is the inverse */
 	std::vector<int32_t> perm[2], inv[2];
@@ -137,6 +139,7 @@ struct blz_ctx {
 	hipStream_t cstream = nullptr;
 	hipEvent_t ev_snap_go = nullptr, ev_snap_done = nullptr;
 	void *snap_host[2] = { nullptr, nullptr };
+	void *snap_dev[2] = { nullptr, nullptr };	/* device-side copy the D2H reads from while the loop goes on (nullptr: no room) */
 	size_t snap_bytes = 0;
 	bool snap_pending = false;
 	int64_t snap_iterations = 0;
@@ -292,6 +295,8 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	c->max_dot_blocks = c->cfg.num_cu * (np_ <= 8 ? 16 : 8);
 	HIPCHK(hipMalloc(&c->partial, (size_t)c->max_dot_blocks * 2 * np_ * np_ * sizeof(u64)));
 	HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
+	HIPCHK(hipHostMalloc((void **)&c->ctl_pinned, sizeof(DevCtl), hipHostMallocMapped));
+	HIPCHK(hipHostGetDevicePointer((void **)&c->ctl_pinned_dev, c->ctl_pinned, 0));
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
 	*out = c;
 	return BLZ_OK;
@@ -338,11 +343,14 @@ extern "C" void blz_destroy(blz_ctx *c)
 	if (c->ev_snap_done) hipEventDestroy(c->ev_snap_done);
 	for (void *&h : c->snap_host)
 		if (h) hipHostFree(h);
+	for (void *&d : c->snap_dev)
+		if (d) hipFree(d);
 	if (c->small) hipFree(c->small);
 	if (c->dot_send) hipFree(c->dot_send);
 	if (c->cfg.mfma_img) hipFree(c->cfg.mfma_img);
 	if (c->partial) hipFree(c->partial);
 	if (c->ctl) hipFree(c->ctl);
+	if (c->ctl_pinned) hipHostFree(c->ctl_pinned);
 	if (c->ev0) hipEventDestroy(c->ev0);
 	if (c->ev1) hipEventDestroy(c->ev1);
 	if (c->stream) hipStreamDestroy(c->stream);
@@ -1134,8 +1142,9 @@ static int enqueue_ortho(blz_ctx *c)
 
 static int fetch_ctl(blz_ctx *c)
 {
-	HIPCHK(hipMemcpyAsync(&c->host_ctl, c->ctl, sizeof(DevCtl), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(launch_publish_ctl(c->ctl, c->ctl_pinned_dev, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	c->host_ctl = *c->ctl_pinned;
 	return BLZ_OK;
 }
 
@@ -1367,10 +1376,11 @@ extern "C" int blz_profile_read(blz_ctx *c, double *ms_sum, int64_t *launches)
 /*
  * Asynchronous snapshot of (v, p, iteration count) for checkpoints -- openMP/lanczos_modp.c:1013-1022 stops the loop,
  * and round 1 did too (two synchronous blz_get_block calls and the file write on the loop thread).
- * blz_snapshot_begin: between two blz_iterate calls; enqueues the device-to-host copies of this rank's rows of v and p
- * into pinned staging on a stream of their own and makes the compute stream wait for them (the next iteration's update
- * writes v and p in place), then returns: the host thread goes on enqueuing iterations, the GPU pauses for the PCIe
- * transfer only (2 x 122 MB ~ 5 ms on the GL7d19 shape; config 5's 2 x 6.4 GB ~ 0.26 s per 60 s checkpoint interval).
+ * blz_snapshot_begin: between two blz_iterate calls; copies this rank's rows of v and p device-to-device on the compute
+ * stream (HBM speed), then enqueues the device-to-host copies of that snapshot into pinned staging on a stream of their
+ * own and returns: the loop goes on while PCIe drains the snapshot (measured with a checkpoint every SECOND: 10.8 % loss on
+ * the config-5 quarter shape when the loop waited for the 2 x 1.6 GB transfer, tools/exp_checkpoint.py).  If the two extra
+ * slabs do not fit in HBM the copies read v and p directly and the compute stream waits for them.
  * blz_snapshot_wait: blocks until the copies have landed and unpacks this rank's rows into v / p (original numbering,
  * caller's width).  It touches only the snapshot's own staging and events, so it MAY be called from another host thread
  * (the checkpoint writer) while the owning thread is inside blz_iterate -- the one exception to one-thread-per-handle.
@@ -1387,19 +1397,37 @@ extern "C" int blz_snapshot_begin(blz_ctx *c)
 	}
 	const size_t bytes = (size_t)std::max<int64_t>(c->count[0], 1) * c->cfg.n * c->cfg.word;
 	if (bytes > c->snap_bytes) {
-		for (void *&h : c->snap_host) {
-			if (h) hipHostFree(h);
-			h = nullptr;
-			HIPCHK(hipHostMalloc(&h, bytes, hipHostMallocDefault));
+		for (int b = 0; b < 2; b++) {
+			if (c->snap_host[b]) hipHostFree(c->snap_host[b]);
+			if (c->snap_dev[b]) hipFree(c->snap_dev[b]);
+			c->snap_host[b] = c->snap_dev[b] = nullptr;
+			HIPCHK(hipHostMalloc(&c->snap_host[b], bytes, hipHostMallocDefault));
+		}
+		/* two more slabs of HBM let the PCIe transfer run beside the loop; without them the loop waits for it */
+		if (hipMalloc(&c->snap_dev[0], bytes) != hipSuccess || hipMalloc(&c->snap_dev[1], bytes) != hipSuccess) {
+			(void)hipGetLastError();
+			for (void *&d : c->snap_dev) {
+				if (d) hipFree(d);
+				d = nullptr;
+			}
 		}
 		c->snap_bytes = bytes;
 	}
+	const bool staged = c->snap_dev[0] && c->snap_dev[1];
+	if (staged) {
+		/* device-to-device on the compute stream by a streaming kernel (2 x slab at HBM speed: 1.3 ms for 2 x 1.6 GB; the
+		 * runtime's own device-to-device copy cost ~60 ms here), then the host copy reads
+		 * the snapshot while later iterations overwrite v and p */
+		HIPCHK(launch_copy(c->cfg, c->snap_dev[0], c->slab[BLZ_V], bytes, c->stream));
+		HIPCHK(launch_copy(c->cfg, c->snap_dev[1], c->slab[BLZ_P], bytes, c->stream));
+	}
 	HIPCHK(hipEventRecord(c->ev_snap_go, c->stream));
 	HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_snap_go, 0));
-	HIPCHK(hipMemcpyAsync(c->snap_host[0], c->slab[BLZ_V], bytes, hipMemcpyDeviceToHost, c->cstream));
-	HIPCHK(hipMemcpyAsync(c->snap_host[1], c->slab[BLZ_P], bytes, hipMemcpyDeviceToHost, c->cstream));
+	HIPCHK(hipMemcpyAsync(c->snap_host[0], staged ? c->snap_dev[0] : c->slab[BLZ_V], bytes, hipMemcpyDeviceToHost, c->cstream));
+	HIPCHK(hipMemcpyAsync(c->snap_host[1], staged ? c->snap_dev[1] : c->slab[BLZ_P], bytes, hipMemcpyDeviceToHost, c->cstream));
 	HIPCHK(hipEventRecord(c->ev_snap_done, c->cstream));
-	HIPCHK(hipStreamWaitEvent(c->stream, c->ev_snap_done, 0));	/* later kernels overwrite v and p in place */
+	if (!staged)
+		HIPCHK(hipStreamWaitEvent(c->stream, c->ev_snap_done, 0));	/* later kernels overwrite v and p in place */
 	c->snap_iterations = c->host_ctl.iterations;
 	c->snap_pending = true;
 	return BLZ_OK;
@@ -1412,7 +1440,17 @@ extern "C" int blz_snapshot_wait(blz_ctx *c, uint64_t *v, uint64_t *p, int64_t *
 	if (!c->snap_pending)
 		return blz_fail(BLZ_EINVAL, "blz_snapshot_wait: no snapshot in flight");
 	HIPCHK(hipSetDevice(c->device));
-	HIPCHK(hipEventSynchronize(c->ev_snap_done));
+	/* polled, not hipEventSynchronize: this runs on the writer's thread while the owner keeps launching, and a blocking
+	 * wait inside the runtime held the owner's launches back for the whole transfer (the loop lost as much time as if it
+	 * had waited for the copy itself) */
+	for (;;) {
+		const hipError_t q = hipEventQuery(c->ev_snap_done);
+		if (q == hipSuccess)
+			break;
+		if (q != hipErrorNotReady)
+			return blz_fail(BLZ_EHIP, "blz_snapshot_wait: %s", hipGetErrorString(q));
+		usleep(500);
+	}
 	const int un = c->un, np = c->cfg.n, sd = 0;
 	uint64_t *dst[2] = { v, p };
 	for (int b = 0; b < 2; b++) {

@@ -115,6 +115,12 @@ hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int 
 hipError_t launch_orthogonalize(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows,
 				const u64 *small, const DevCtl *ctl, hipStream_t s);
 
+/* *host_mapped <- *ctl, written by the GPU into host-mapped pinned memory (no copy engine involved) */
+hipError_t launch_publish_ctl(const DevCtl *ctl, DevCtl *host_mapped, hipStream_t s);
+
+/* device-to-device copy by a streaming kernel (HBM speed) */
+hipError_t launch_copy(const KernelCfg &c, void *dst, const void *src, size_t bytes, hipStream_t s);
+
 /* X[i] <- X[i] mod p for 64-bit words that hold sums of a few residues (after a reduce-scatter) */
 hipError_t launch_reduce_modp(const KernelCfg &c, void *X, int64_t words, const DevCtl *ctl, hipStream_t s);
 

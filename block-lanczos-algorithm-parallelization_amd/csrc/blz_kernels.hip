@@ -2327,6 +2327,43 @@ __global__ void __launch_bounds__(BLOCK) k_any_nonzero(const W *__restrict__ X, 
 		atomicOr(flag, 1);
 }
 
+/* the control words, stored to host-mapped pinned memory by the GPU itself: a hipMemcpyAsync of these 24 bytes queues
+ * behind whatever the copy engines are busy with (a checkpoint's 3 GB device-to-host transfer held blz_iterate's return
+ * back by ~100 ms) */
+__global__ void k_publish_ctl(const DevCtl *__restrict__ ctl, DevCtl *__restrict__ host_mapped)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0)
+		*host_mapped = *ctl;
+}
+
+hipError_t launch_publish_ctl(const DevCtl *ctl, DevCtl *host_mapped, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_publish_ctl, dim3(1), dim3(64), 0, s, ctl, host_mapped);
+	return hipGetLastError();
+}
+
+/* dst <- src, 16 bytes per lane (the snapshot of v and p: hipMemcpyAsync device-to-device ran at ~60 GB/s here) */
+__global__ void __launch_bounds__(BLOCK)
+k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, long long n16)
+{
+	const long long step = (long long)gridDim.x * BLOCK;
+	for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += step)
+		dst[i] = src[i];
+}
+
+hipError_t launch_copy(const KernelCfg &c, void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+	const long long n16 = (long long)(bytes / 16);
+	if (n16 > 0) {
+		long long blocks = (n16 + BLOCK * 8 - 1) / (BLOCK * 8);
+		blocks = blocks > (long long)c.num_cu * 8 ? (long long)c.num_cu * 8 : blocks;
+		hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(BLOCK), 0, s, (uint4 *)dst, (const uint4 *)src, n16);
+	}
+	if (bytes % 16)		/* slabs are whole block rows of 4- or 8-byte words: a tail of 4, 8 or 12 bytes at most */
+		return hipMemcpyAsync((char *)dst + n16 * 16, (const char *)src + n16 * 16, bytes % 16, hipMemcpyDeviceToDevice, s);
+	return hipGetLastError();
+}
+
 /* x <- x mod p, words that are sums of a few residues (the reduce-scatter of partial products) */
 template <int MERS>
 __global__ void __launch_bounds__(BLOCK)

@@ -35,9 +35,10 @@ def run(with_ckpt):
         state["busy"] = False
 
     th = None
+    ctx.sync()
     t0 = last = time.time()
     its = 0
-    while time.time() - t0 < seconds:
+    while its < target:
         done, stopped, _ = ctx.iterate(batch)
         its += done
         assert not stopped
@@ -59,6 +60,7 @@ def run(with_ckpt):
                 writer_s=round(state["write_s"], 2))
 
 
+target = max(batch, int(seconds / 0.25) * batch)      # the same number of iterations in both runs
 plain = run(False)
 ck = run(True)
 print(json.dumps(dict(workload=name, n=n, block_MB=round(ctx.rows(blz.V) * n * 8 / 1e6), batch=batch, every_s=every, plain=plain,
