@@ -1118,10 +1118,10 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D)
 		 * already hit L1.  BLZ_STAGE_ALWAYS=1 stages every slab (PMC comparisons). */
 		const double a = D.kept_mean >= 0.0 ? D.kept_mean : (double)D.nnz / (double)D.rows;
 		const char *e = getenv("BLZ_STAGE_ALWAYS");
-		/* (block rows of 128 bytes and more, G >= 16: a wavefront holds four lane groups or fewer, each streaming its own
-		 * row -- 130 M stream requests per launch where 16 M lines would do on the config-5 quarter shape,
-		 * profiles/r02_synth5q_pmc.txt -- staging wins at every row length: 13.1 -> 12.4 ms) */
-		if (!(e && e[0] == '1') && G <= 8 && a >= 12.0 && a < 48.0)
+		/* (the same holds at 128-byte block rows: GL7d19 shape at n = 16, rows of 19.5: 722 -> 779 us staged, while the
+		 * config-5 quarter shape, rows of 40, gains: 13.1 -> 12.4 ms -- there 130 M stream requests per launch become
+		 * 16 M lines, profiles/r02_synth5q_pmc.txt.  The boundary is put at 32 entries.) */
+		if (!(e && e[0] == '1') && a >= 12.0 && a < 32.0)
 			return;
 	}
 	const int GPW = 64 / G, NS = (D.val && !D.palette) ? 2 : 1;
