@@ -1352,6 +1352,17 @@ int blz_prepared_slab_short(const blz_prepared *P, int rank, int t, blz_csr *out
 	return BLZ_OK;
 }
 
+int blz_prepared_layout(const blz_prepared *P, int64_t *bounds0, int64_t *bounds1, int64_t stride[2])
+{
+	if (!P || !bounds0 || !bounds1 || !stride)
+		return blz_fail(BLZ_EINVAL, "blz_prepared_layout: NULL argument");
+	memcpy(bounds0, P->bounds[0], sizeof(int64_t) * (size_t)(P->nranks + 1));
+	memcpy(bounds1, P->bounds[1], sizeof(int64_t) * (size_t)(P->nranks + 1));
+	stride[0] = P->stride[0];
+	stride[1] = P->stride[1];
+	return BLZ_OK;
+}
+
 int blz_prepared_describe(const blz_prepared *P, int *right, int *nranks, int *chunks)
 {
 	if (!P)

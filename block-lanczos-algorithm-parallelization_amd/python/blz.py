@@ -205,6 +205,16 @@ class Prepared:
         lib().blz_csr_free(C.byref(A))
         return out
 
+    def layout(self):
+        """(right, nranks, chunks, bounds of side 0, bounds of side 1, strides)"""
+        r, nr, ch = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().blz_prepared_describe(self.h, C.byref(r), C.byref(nr), C.byref(ch)))
+        b0 = (C.c_int64 * (nr.value + 1))()
+        b1 = (C.c_int64 * (nr.value + 1))()
+        st = (C.c_int64 * 2)()
+        check(lib().blz_prepared_layout(self.h, b0, b1, st))
+        return bool(r.value), nr.value, ch.value, list(b0), list(b1), list(st)
+
     def slab_short(self, rank, t):
         """blz_prepared_slab_short(): product t in its short-side form for rank `rank`."""
         A = Csr()

@@ -144,6 +144,8 @@ int blz_prepare(const blz_coo *M, int right, int nranks, int chunks, int reorder
 int blz_prepared_save(const blz_prepared *P, const char *path, uint64_t key);
 int blz_prepared_load(const char *path, uint64_t key, blz_prepared **out);
 void blz_prepared_free(blz_prepared *P);
+/* the row partition: bounds0 / bounds1 [nranks + 1] of side 0 (rows of v) / side 1 (rows of tmp), rows of a padded slab per side */
+int blz_prepared_layout(const blz_prepared *P, int64_t *bounds0, int64_t *bounds1, int64_t stride[2]);
 /* what P was prepared for (any pointer may be NULL) */
 int blz_prepared_describe(const blz_prepared *P, int *right, int *nranks, int *chunks);
 /* rank `rank`'s rows of M (t = 0) or of M^T (t = 1) as a CSR of its own, columns rewritten to positions in the gathered
