@@ -261,6 +261,16 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 		c->cfg.staged = !(ns && ns[0] == '1');
 	}
 	{
+		const char *nsd = getenv("BLZ_NO_SIDE");
+		c->cfg.side = nullptr;
+		c->cfg.ev_fork = c->cfg.ev_join = nullptr;
+		if (!(nsd && nsd[0] == '1')) {
+			HIPCHK(hipStreamCreateWithFlags(&c->cfg.side, hipStreamNonBlocking));
+			HIPCHK(hipEventCreateWithFlags(&c->cfg.ev_fork, hipEventDisableTiming));
+			HIPCHK(hipEventCreateWithFlags(&c->cfg.ev_join, hipEventDisableTiming));
+		}
+	}
+	{
 		const char *nm = getenv("BLZ_NO_MFMA");
 		c->cfg.mfma = !(nm && nm[0] == '1');
 		c->cfg.mfma_img = nullptr;
@@ -348,6 +358,12 @@ extern "C" void blz_destroy(blz_ctx *c)
 	if (c->small) hipFree(c->small);
 	if (c->dot_send) hipFree(c->dot_send);
 	if (c->cfg.mfma_img) hipFree(c->cfg.mfma_img);
+	if (c->cfg.side) {
+		hipStreamSynchronize(c->cfg.side);
+		hipStreamDestroy(c->cfg.side);
+	}
+	if (c->cfg.ev_fork) hipEventDestroy(c->cfg.ev_fork);
+	if (c->cfg.ev_join) hipEventDestroy(c->cfg.ev_join);
 	if (c->partial) hipFree(c->partial);
 	if (c->ctl) hipFree(c->ctl);
 	if (c->ctl_pinned) hipHostFree(c->ctl_pinned);

@@ -70,6 +70,8 @@ struct KernelCfg {
 	ModP m;
 	int num_cu;
 	int spmv_blocks_per_cu;	/* grid of the persistent SpMV = num_cu * this (BLZ_SPMV_BLOCKS_PER_CU overrides) */
+	hipStream_t side;	/* stream of the outlier-row launches (nullptr: same stream as the streaming kernel; BLZ_NO_SIDE=1) */
+	hipEvent_t ev_fork, ev_join;
 	int mfma;		/* 1: the dense row kernels use the matrix cores where they can (p = 2^61-1, n = 8 / 16); BLZ_NO_MFMA=1 */
 	void *mfma_img;		/* device scratch for the coefficient digits in MFMA fragment order (ortho_mfma_image_bytes()) */
 	int panel;		/* 1: slabs whose operand has hot block rows run k_spmv_panel; BLZ_NO_PANEL=1 turns it off */
