@@ -11,47 +11,61 @@
  *   - a block row in HBM is already the A operand: its bytes are the base-256 digits of its words, in the order
  *     K' = (word k, byte a).  A lane takes 16 of them with one 16-byte load; XOR 0x80 turns a byte u into u - 128,
  *     which fits the instruction's signed 8-bit inputs.
- *   - the n x n coefficients are rewritten once per launch (k_ortho_mfma_prep) as SIGNED base-256 digits d_b in
- *     [-128, 127] (9 digits with the carry), so that no bias is needed on that side.  For every s = a + b (0..15) the
- *     B operand B_s[(k,a)][j] = d_{s-a}(coef[k][j]) sits in LDS in fragment order.
- *   - acc_s[r][j] = sum over K' of (u - 128) * B_s  is one chain of 2..4 MFMAs; the accumulator starts at
- *     128 * (column sum of B_s) + 2^24, which removes the bias of A and keeps the digit sum S_s non-negative (< 2^25).
- *   - the result sum_s S_s * 2^(8 s) is folded mod 2^61 - 1 on the fly: 2^(8 s) = 2^(8 s mod 61), every term is ONE
- *     v_mad_u64_u32 into one of two 64-bit sums (shifts 0..27 and 32..59), then one 128-bit fold.  The 2^24 biases add up
- *     to a constant that is subtracted mod p at the end.
+ *   - byte a of word k weighs 2^(8a): the n x n coefficients are rewritten once per launch (k_ortho_mfma_prep) as
+ *     coef[k][j] * 2^(8a) mod p -- a rotation of the 61-bit word, p being 2^61 - 1 -- one 61-bit multiplier per K' = (k, a),
+ *     and each multiplier as 8 SIGNED base-256 digits d_t in [-128, 127], so that no bias is needed on that side.  For
+ *     every digit position t (0..7) the B operand B_t[(k,a)][j] = d_t(coef[k][j] 2^(8a) mod p) sits in LDS in fragment
+ *     order.  (Contracting digit against digit by s = a + b instead needs 16 digit sums: twice the MFMAs, LDS reads and
+ *     folding work.  That was the first version of this kernel.)
+ *   - acc_t[r][j] = sum over K' of (u - 128) * B_t  is one chain of 2..4 MFMAs; the accumulator starts at
+ *     128 * (column sum of B_t) + 2^24, which removes the bias of A and keeps the digit sum S_t positive (< 2^25).
+ *   - the result sum_t S_t * 2^(8 t) needs no wrap (t < 8): every term is ONE v_mad_u64_u32 into one of two 64-bit sums
+ *     (t < 4 and t >= 4), then one 128-bit fold mod 2^61 - 1.  The 2^24 biases add up to a constant that is subtracted
+ *     mod p at the end.
  * Everything is integer and exact, so the words written are the ones the VALU kernels (and the reference) write.
  *
- * n = 16: two chains per 16-row tile, [v | p] x [c ; vtAvd] (K' = 256, 4 MFMAs per s) and v x winv (K' = 128, 2 per s).
- * n = 8:  one chain, [v | p] x [[c | winv] ; [vtAvd | 0]] (K' = 128, 2 per s): columns 0..7 of the tile are v', 8..15 p'.
+ * n = 16: two chains per 16-row tile, [v | p] x [c ; vtAvd] (K' = 256, 4 MFMAs per t) and v x winv (K' = 128, 2 per t).
+ * n = 8:  one chain, [v | p] x [[c | winv] ; [vtAvd | 0]] (K' = 128, 2 per t): columns 0..7 of the tile are v', 8..15 p'.
  */
 #include "blz_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-#define MBLOCK 512
+#define MBLOCK 256
 
 template <int NT>
 struct OG {
 	static constexpr int KS1 = NT == 16 ? 4 : 2, KS2 = NT == 16 ? 2 : 0, KS = KS1 + KS2, NCH = NT == 16 ? 2 : 1;
-	static constexpr size_t B_BYTES = (size_t)KS * 16 * 64 * 16, INIT_BYTES = (size_t)NCH * 16 * 16 * 4;
-	static constexpr size_t IMG_BYTES = B_BYTES + INIT_BYTES + 16;
+	static constexpr int ND = 8;		/* digit positions of a multiplier */
+	static constexpr size_t B_BYTES = (size_t)KS * ND * 64 * 16, INIT_BYTES = (size_t)NCH * ND * 16 * 4;
+	static constexpr size_t IMG_BYTES = B_BYTES + INIT_BYTES;
+	/* n = 16 stages the rows through LDS; per wavefront 16 rows of v and 16 of p, row stride = row bytes + 16 (bank spread) */
+	static constexpr bool STAGED = NT == 16;
+	static constexpr bool PREFETCH = NT == 16;	/* load the next tile during the arithmetic: n = 8 lost by it (150 vs 124 us) */
+	static constexpr int RSTR = NT * 8 + 16;
+	static constexpr size_t STAGE_BYTES = STAGED ? (size_t)2 * 16 * RSTR : 0;
+	static constexpr size_t LDS_BYTES = IMG_BYTES + (MBLOCK / 64) * STAGE_BYTES;
 };
 
 /* weight of digit sum s in the folded result: 2^(8 s mod 61), applied as a 32-bit multiplier into L (shift < 32) or H */
 __host__ __device__ constexpr int fold_shift(int s) { return (8 * s) % 61; }
 
-/* signed base-256 digits of x < 2^62: x = sum d_b 256^b, d_b in [-128, 127], b = 0..8 */
-__device__ static void signed_digits(u64 x, signed char *d)
+/* digit t (signed, base 256) of x < 2^62: with C = 0x8080...80, x = sum_t (byte_t(x + C) - 128) 256^t and every
+ * byte_t - 128 lies in [-128, 127]; x + C does not wrap. */
+MODP_DEV int signed_digit(u64 x, int t)
 {
-	int carry = 0;
-	for (int b = 0; b < 8; b++) {
-		int t = (int)((x >> (8 * b)) & 0xFF) + carry;
-		carry = t >= 128;
-		d[b] = (signed char)(carry ? t - 256 : t);
-	}
-	d[8] = (signed char)carry;
+	return (int)(((x + 0x8080808080808080ull) >> (8 * t)) & 0xFF) - 128;
+}
+
+/* x * 2^sh mod 2^61 - 1 for x < 2^61, sh < 61: a rotation of the 61-bit word */
+MODP_DEV u64 rot61(u64 x, int sh)
+{
+	const u64 P = (1ull << 61) - 1;
+	const u64 r = ((x << sh) & P) | (x >> (61 - sh));
+	return sh == 0 ? x : (r == P ? 0 : r);
 }
 
 /* coefficient of K' word kk and tile column col for chain ch: which matrix, which entry (or none) */
@@ -69,58 +83,61 @@ __device__ static int coef_index(int ch, int kk, int col)
 	return kk < 8 ? 2 * 64 + kk * 8 + (col - 8) : -1;
 }
 
+/* coefficient of word kk and tile column col in chain ch (0 where the chain has none); the multiplier of K' = (kk, byte a)
+ * is rot61(coefficient, 8 a) = coefficient * 2^(8a) mod p */
+template <int NT>
+__device__ static u64 coefficient(const u64 *small, int ch, int kk, int col)
+{
+	constexpr int NN = NT * NT;
+	const int ci = coef_index<NT>(ch, kk, col);
+	if (ci < 0)
+		return 0;
+	const int mat = ci / NN, at = ci % NN;
+	return small[(mat == 0 ? 4 : (mat == 1 ? 5 : 2)) * NN + at];
+}
+
 template <int NT>
 __global__ void __launch_bounds__(256)
-k_ortho_mfma_prep(const u64 *__restrict__ small, unsigned char *__restrict__ img, u64 p, const DevCtl *__restrict__ ctl)
+k_ortho_mfma_prep(const u64 *__restrict__ small, unsigned char *__restrict__ img, const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
-	constexpr int NN = NT * NT;
 	using G = OG<NT>;
-	__shared__ signed char dig[3 * NN][9];
 	const int t = threadIdx.x;
-	for (int e = t; e < 3 * NN; e += 256) {
-		const int mat = e / NN, at = e % NN;
-		const u64 x = small[(mat == 0 ? 4 : (mat == 1 ? 5 : 2)) * NN + at];
-		signed_digits(x, dig[e]);
-	}
-	__syncthreads();
 	signed char *B = (signed char *)img;
 	int *init = (int *)(img + G::B_BYTES);
+	/* fragment order: [K step ks][digit position][lane][16 bytes]; lane = 16 (K' / 16 within the step) + column */
 	for (int idx = blockIdx.x * 256 + t; idx < (int)G::B_BYTES; idx += gridDim.x * 256) {
-		const int j = idx & 15, ln = (idx >> 4) & 63, s = (idx >> 10) & 15, ks = idx >> 14;
+		const int j = idx & 15, ln = (idx >> 4) & 63, dg = (idx >> 10) & 7, ks = idx >> 13;
 		const int ch = ks < G::KS1 ? 0 : 1, kc = ch == 0 ? ks : ks - G::KS1;
-		const int E = 64 * kc + 16 * (ln >> 4) + j, kk = E >> 3, a = E & 7, b = s - a;
-		const int ci = coef_index<NT>(ch, kk, ln & 15);
-		B[idx] = (ci >= 0 && b >= 0 && b <= 8) ? dig[ci][b] : (signed char)0;
+		const int E = 64 * kc + 16 * (ln >> 4) + j;
+		B[idx] = (signed char)signed_digit(rot61(coefficient<NT>(small, ch, E >> 3, ln & 15), 8 * (E & 7)), dg);
 	}
 	if (blockIdx.x != 0)
 		return;
-	/* accumulator start: 128 * (sum over K' of B_s[.][col]) + 2^24 */
-	for (int e = t; e < G::NCH * 16 * 16; e += 256) {
-		const int col = e & 15, s = (e >> 4) & 15, ch = e >> 8;
+	/* accumulator start: 128 * (sum over K' of B_t[.][col]) + 2^24 */
+	for (int e = t; e < G::NCH * G::ND * 16; e += 256) {
+		const int col = e & 15, dg = (e >> 4) & 7, ch = e >> 7;
 		const int words = ch == 0 ? G::KS1 * 8 : G::KS2 * 8;
 		int sum = 0;
 		for (int kk = 0; kk < words; kk++) {
-			const int ci = coef_index<NT>(ch, kk, col);
-			if (ci < 0)
-				continue;
-			for (int a = 0; a < 8; a++) {
-				const int b = s - a;
-				if (b >= 0 && b <= 8)
-					sum += dig[ci][b];
-			}
+			const u64 x = coefficient<NT>(small, ch, kk, col);
+			for (int a = 0; a < 8; a++)
+				sum += signed_digit(rot61(x, 8 * a), dg);
 		}
 		init[e] = 128 * sum + (1 << 24);
 	}
-	if (t == 0) {
-		/* the 2^24 added to each of the 16 digit sums, with their fold weights: subtract it at the end */
-		unsigned __int128 bias = 0;
-		for (int s = 0; s < 16; s++)
-			bias += (unsigned __int128)(1u << 24) << fold_shift(s);
-		const u64 r = (u64)(bias % p);
-		*(u64 *)(img + G::B_BYTES + G::INIT_BYTES) = r ? p - r : 0;
-	}
+}
+
+/* the 2^24 added to each of the 8 digit sums, with their weights 2^(8 t): minus their sum mod 2^61 - 1, added at the end */
+constexpr u64 ortho_bias_correction(void)
+{
+	const u64 P = (1ull << 61) - 1;
+	unsigned __int128 bias = 0;
+	for (int dg = 0; dg < 8; dg++)
+		bias += (unsigned __int128)(1u << 24) << (8 * dg);
+	const u64 r = (u64)(bias % P);
+	return r ? P - r : 0;
 }
 
 /* acc += a * b (32 x 32 -> 64, 64-bit add).  Plain C on purpose: the operands come straight out of an MFMA, and the compiler
@@ -134,7 +151,7 @@ MODP_DEV void mad_u64(u64 &acc, u32 a, u32 b)
 
 MODP_DEV u64 fold61(u64 L, u64 H)
 {
-	/* value = L + H * 2^32 (L < 2^61, H < 2^56): fold mod 2^61 - 1 */
+	/* value = L + H * 2^32 (L < 2^61, H < 2^56; here both < 2^50): fold mod 2^61 - 1 */
 	const u64 P = (1ull << 61) - 1;
 	const u64 lo = L + (H << 32), carry = lo < L;
 	const u64 hi = (H >> 32) + carry;
@@ -143,7 +160,52 @@ MODP_DEV u64 fold61(u64 L, u64 H)
 	return x >= P ? x - P : x;
 }
 
+/* What a wavefront holds of one 16-row tile between the loads and their use: the rows of v and p, and the terms that are
+ * not products, already in the accumulator layout (row 4 h + reg, column col).
+ * n = 16 (128-byte rows): the rows are loaded as they lie in memory (lane l has bytes 16 l .. 16 l + 15 of the tile's first
+ * KB, then of the second, so every load instruction covers whole lines) and pass through LDS to become A fragments: loading
+ * fragments directly makes each quarter-wavefront touch 16 lines for 16 bytes each, four times per row, and the kernel
+ * got SLOWER with more wavefronts per CU (2.32 ms at 12, 1.95 ms at 8; staged 1.81 ms).
+ * n = 8 (64-byte rows): a fragment load covers 1 KB of consecutive rows anyway; staging cost more than it gave (147 vs 124 us). */
 template <int NT>
+struct OrthoTile {
+	static constexpr int NLD = NT / 8;		/* 16-byte loads per lane and block: 16 rows x 8 NT bytes / 1 KB */
+	v4i a[2 * NLD];
+	u64 b1[4], b2[4];
+};
+
+template <int NT>
+MODP_DEV void ortho_tile_load(OrthoTile<NT> &R, const u64 *V, const u64 *AV, const u64 *Pb, long long rows, long long tile,
+			      int lane, int h, int jout, bool is_p, bool dj)
+{
+	constexpr int ROWB = NT * 8, NLD = OrthoTile<NT>::NLD;
+	const long long r0 = tile << 4;
+#pragma unroll
+	for (int q = 0; q < NLD; q++) {
+		/* staged: byte o of the tile; direct: row m = lane & 15, bytes 16 h .. of its 64-byte part q */
+		const int o = OG<NT>::STAGED ? 16 * lane + 1024 * q : (lane & 15) * ROWB + 64 * q + 16 * h;
+		long long rr = r0 + o / ROWB;
+		rr = rr < rows ? rr : rows - 1;		/* rows past the end: any valid address, the results are not stored */
+		const size_t at = (size_t)rr * ROWB + (o % ROWB);
+		R.a[q] = *(const v4i *)((const unsigned char *)V + at);
+		R.a[NLD + q] = *(const v4i *)((const unsigned char *)Pb + at);
+	}
+#pragma unroll
+	for (int reg = 0; reg < 4; reg++) {
+		long long rr = r0 + 4 * h + reg;
+		rr = rr < rows ? rr : rows - 1;
+		const size_t at = (size_t)rr * NT + jout;
+		if (NT == 16) {
+			R.b1[reg] = dj ? AV[at] : V[at];
+			R.b2[reg] = dj ? 0 : Pb[at];
+		} else {
+			R.b1[reg] = is_p ? (dj ? 0 : Pb[at]) : (dj ? AV[at] : V[at]);
+			R.b2[reg] = 0;
+		}
+	}
+}
+
+template <int NT, bool PF>
 __global__ void __launch_bounds__(MBLOCK)
 k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ Pb, long long rows,
 	     const u64 *__restrict__ small, const unsigned char *__restrict__ img, const DevCtl *__restrict__ ctl)
@@ -152,82 +214,96 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 		return;
 	using G = OG<NT>;
 	constexpr int NN = NT * NT;
+	constexpr int ROWB = NT * 8, NLD = OrthoTile<NT>::NLD;
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	{
 		const uint4 *src = (const uint4 *)img;
 		uint4 *dst = (uint4 *)lds;
-		for (int i = threadIdx.x; i < (int)((G::B_BYTES + G::INIT_BYTES + 16) / 16); i += MBLOCK)
+		for (int i = threadIdx.x; i < (int)(G::IMG_BYTES / 16); i += MBLOCK)
 			dst[i] = src[i];
 	}
 	__syncthreads();
 	const v4i *Bl = (const v4i *)lds;
 	const int *init = (const int *)(lds + G::B_BYTES);
-	const u64 fconst = *(const u64 *)(lds + G::B_BYTES + G::INIT_BYTES);
+	constexpr u64 fconst = ortho_bias_correction();
 	const u64 PR = (1ull << 61) - 1;
 	u32 one;
 	asm volatile("s_mov_b32 %0, 1" : "=s"(one));	/* 1, opaque to the optimiser (see mad_u64) */
 	const int lane = threadIdx.x & 63, m = lane & 15, h = lane >> 4, col = m;
+	/* this wavefront's staging area: the tile's rows of v, then of p, each row padded by 16 bytes so that the 16 rows a
+	 * fragment read touches fall on different banks */
+	unsigned char *stage = lds + G::IMG_BYTES + (threadIdx.x >> 6) * G::STAGE_BYTES;
 	const long long wave = ((long long)blockIdx.x * MBLOCK + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * MBLOCK) >> 6;
 	const long long ntiles = (rows + 15) >> 4;
 	/* which output this lane's tile column is, and its selector d */
 	const int jout = NT == 16 ? col : (col & 7);
 	const bool is_p = NT == 8 && col >= 8;
 	const bool dj = small[3 * NN + jout] != 0;
+	OrthoTile<NT> R;
+	if (PF && wave < ntiles)
+		ortho_tile_load<NT>(R, V, AV, Pb, rows, wave, lane, h, jout, is_p, dj);
 	for (long long tile = wave; tile < ntiles; tile += nwaves) {
 		const long long r0 = tile << 4;
-		long long ra = r0 + m;
-		ra = ra < rows ? ra : rows - 1;
-		/* A fragments: 16 bytes of the row per K-step, biased to signed */
+		if (!PF)
+			ortho_tile_load<NT>(R, V, AV, Pb, rows, tile, lane, h, jout, is_p, dj);
+		/* A fragments: row m, 16 bytes per K-step, biased to signed */
 		v4i A[G::KS1];
-		if (NT == 16) {
-			A[0] = *(const v4i *)(V + (size_t)ra * 16 + 2 * h);
-			A[1] = *(const v4i *)(V + (size_t)ra * 16 + 8 + 2 * h);
-			A[2] = *(const v4i *)(Pb + (size_t)ra * 16 + 2 * h);
-			A[3] = *(const v4i *)(Pb + (size_t)ra * 16 + 8 + 2 * h);
-		} else {
-			A[0] = *(const v4i *)(V + (size_t)ra * 8 + 2 * h);
-			A[1] = *(const v4i *)(Pb + (size_t)ra * 8 + 2 * h);
-		}
-		/* the terms that are not products, in the accumulator layout: row 4 h + reg, column col */
-		u64 base1[4], base2[4];
+		if (G::STAGED) {
+			/* rows -> LDS as loaded, and back in fragment order */
 #pragma unroll
-		for (int reg = 0; reg < 4; reg++) {
-			long long rr = r0 + 4 * h + reg;
-			rr = rr < rows ? rr : rows - 1;
-			const size_t at = (size_t)rr * NT + jout;
-			if (NT == 16) {
-				base1[reg] = dj ? AV[at] : V[at];
-				base2[reg] = dj ? 0 : Pb[at];
-			} else {
-				base1[reg] = is_p ? (dj ? 0 : Pb[at]) : (dj ? AV[at] : V[at]);
-				base2[reg] = 0;
+			for (int q = 0; q < NLD; q++) {
+				const int o = 16 * lane + 1024 * q;
+				const int at = (o / ROWB) * G::RSTR + (o % ROWB);
+				*(v4i *)(stage + at) = R.a[q];
+				*(v4i *)(stage + 16 * G::RSTR + at) = R.a[NLD + q];
 			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int q = 0; q < G::KS1; q++) {
+				const int arr = q / NLD, part = q % NLD;		/* 0 = v, 1 = p; 64-byte part of the row */
+				A[q] = *(const v4i *)(stage + arr * 16 * G::RSTR + m * G::RSTR + 64 * part + 16 * h);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		} else {
+#pragma unroll
+			for (int q = 0; q < G::KS1; q++)
+				A[q] = R.a[q];
 		}
 #pragma unroll
 		for (int q = 0; q < G::KS1; q++)
 			A[q] ^= (v4i){ (int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080 };
+		u64 base1[4], base2[4];
+#pragma unroll
+		for (int reg = 0; reg < 4; reg++) {
+			base1[reg] = R.b1[reg];
+			base2[reg] = R.b2[reg];
+		}
+		/* the next tile's loads fly during this tile's arithmetic */
+		if (PF && tile + nwaves < ntiles)
+			ortho_tile_load<NT>(R, V, AV, Pb, rows, tile + nwaves, lane, h, jout, is_p, dj);
 		u64 L1[4] = { 0, 0, 0, 0 }, H1[4] = { 0, 0, 0, 0 }, L2[4] = { 0, 0, 0, 0 }, H2[4] = { 0, 0, 0, 0 };
 #pragma unroll
-		for (int s = 0; s < 16; s++) {
-			const int i1 = init[(0 * 16 + s) * 16 + col];
+		for (int s = 0; s < G::ND; s++) {
+			const int i1 = init[(0 * G::ND + s) * 16 + col];
 			v4i acc1 = { i1, i1, i1, i1 };
 #pragma unroll
 			for (int ks = 0; ks < G::KS1; ks++)
-				acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks], Bl[(ks * 16 + s) * 64 + lane], acc1, 0, 0, 0);
+				acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks], Bl[(ks * G::ND + s) * 64 + lane], acc1, 0, 0, 0);
 			v4i acc2 = { 0, 0, 0, 0 };
 			if (NT == 16) {
-				const int i2 = init[(1 * 16 + s) * 16 + col];
+				const int i2 = init[(1 * G::ND + s) * 16 + col];
 				acc2 = (v4i){ i2, i2, i2, i2 };
 #pragma unroll
 				for (int ks = 0; ks < G::KS2; ks++)
-					acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks], Bl[((G::KS1 + ks) * 16 + s) * 64 + lane], acc2, 0, 0, 0);
+					acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks], Bl[((G::KS1 + ks) * G::ND + s) * 64 + lane], acc2, 0, 0, 0);
 			}
-			const int sh = fold_shift(s);
-			const u32 mul = one << (sh < 32 ? sh : sh - 32);
+			const u32 mul = one << (s < 4 ? 8 * s : 8 * (s - 4));
 #pragma unroll
 			for (int reg = 0; reg < 4; reg++) {
 				/* one v_mad_u64_u32 per digit sum (the compiler would shift and add: three instructions) */
-				if (sh < 32) {
+				if (s < 4) {
 					mad_u64(L1[reg], (u32)acc1[reg], mul);
 					if (NT == 16)
 						mad_u64(L2[reg], (u32)acc2[reg], mul);
@@ -237,7 +313,7 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 						mad_u64(H2[reg], (u32)acc2[reg], mul);
 				}
 			}
-			/* keep the digit sums sequential: without this the compiler hoists all 16 x KS fragment reads (and spills) */
+			/* keep the digit sums sequential: without this the compiler hoists all the fragment reads (and spills) */
 			asm volatile("" ::: "memory");
 		}
 #pragma unroll
@@ -271,6 +347,29 @@ bool ortho_mfma_supported(const KernelCfg &c)
 	return c.mfma && c.mfma_img && c.word == 8 && c.mers == 61 && (c.n == 8 || c.n == 16);
 }
 
+/* workgroups of k_ortho_mfma<NT> one CU holds (registers and the LDS image decide), asked once per device */
+template <int NT>
+static int ortho_mfma_blocks_per_cu(void)
+{
+	static int per_cu[64] = { 0 };
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if (dev >= 0 && dev < 64 && per_cu[dev] > 0)
+		return per_cu[dev];
+	int k = 0;
+	/* more than 64 KB of dynamic LDS needs the attribute, once per DEVICE (several contexts of one process) */
+	if (OG<NT>::LDS_BYTES > 65536)
+		(void)hipFuncSetAttribute((const void *)k_ortho_mfma<NT, OG<NT>::PREFETCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OG<NT>::LDS_BYTES);
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, (const void *)k_ortho_mfma<NT, OG<NT>::PREFETCH>, MBLOCK, OG<NT>::LDS_BYTES) != hipSuccess || k < 1)
+		k = 1;
+	const char *e = getenv("BLZ_MFMA_PER_CU");	/* experiments */
+	if (e && atoi(e) > 0 && atoi(e) < k)
+		k = atoi(e);
+	if (dev >= 0 && dev < 64)
+		per_cu[dev] = k;
+	return k;
+}
+
 hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows, const u64 *small,
 				     const DevCtl *ctl, hipStream_t s)
 {
@@ -278,27 +377,28 @@ hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV
 		return hipSuccess;
 	const long long ntiles = (rows + 15) / 16;
 	long long blocks = (ntiles + MBLOCK / 64 - 1) / (MBLOCK / 64);
-	/* the B image sits in LDS: 98 KB at n = 16 (one workgroup of 8 wavefronts per CU), 33 KB at n = 8 (two: 120 VGPRs) */
-	const long long cap = (long long)c.num_cu * (c.n == 16 ? 1 : 2);
+	/* the B image sits in LDS: 49 KB at n = 16, 16 KB at n = 8; a persistent grid of as many workgroups as fit */
+	const long long cap = (long long)c.num_cu * (c.n == 16 ? ortho_mfma_blocks_per_cu<16>() : ortho_mfma_blocks_per_cu<8>());
 	blocks = blocks > cap ? cap : blocks;
 	unsigned char *img = (unsigned char *)c.mfma_img;
+	static const char *pfe = getenv("BLZ_MFMA_PREFETCH");		/* experiments: 0 / 1 overrides the measured choice */
+	const bool pf = pfe ? atoi(pfe) != 0 : (c.n == 16 ? OG<16>::PREFETCH : OG<8>::PREFETCH);
 	if (c.n == 16) {
-		/* more than 64 KB of dynamic LDS needs the attribute, once per DEVICE (several contexts of one process) */
-		static bool attr[64] = { false };
-		int dev = 0;
-		(void)hipGetDevice(&dev);
-		if (dev < 0 || dev >= 64 || !attr[dev]) {
-			(void)hipFuncSetAttribute((const void *)k_ortho_mfma<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OG<16>::IMG_BYTES);
-			if (dev >= 0 && dev < 64)
-				attr[dev] = true;
-		}
-		hipLaunchKernelGGL((k_ortho_mfma_prep<16>), dim3(32), dim3(256), 0, s, small, img, c.m.p, ctl);
-		hipLaunchKernelGGL((k_ortho_mfma<16>), dim3((unsigned)blocks), dim3(MBLOCK), OG<16>::IMG_BYTES, s, (u64 *)V, (const u64 *)AV,
-				   (u64 *)P, (long long)rows, small, img, ctl);
+		hipLaunchKernelGGL((k_ortho_mfma_prep<16>), dim3(32), dim3(256), 0, s, small, img, ctl);
+		if (pf)
+			hipLaunchKernelGGL((k_ortho_mfma<16, true>), dim3((unsigned)blocks), dim3(MBLOCK), OG<16>::LDS_BYTES, s, (u64 *)V,
+					   (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
+		else
+			hipLaunchKernelGGL((k_ortho_mfma<16, false>), dim3((unsigned)blocks), dim3(MBLOCK), OG<16>::LDS_BYTES, s, (u64 *)V,
+					   (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
 	} else {
-		hipLaunchKernelGGL((k_ortho_mfma_prep<8>), dim3(16), dim3(256), 0, s, small, img, c.m.p, ctl);
-		hipLaunchKernelGGL((k_ortho_mfma<8>), dim3((unsigned)blocks), dim3(MBLOCK), OG<8>::IMG_BYTES, s, (u64 *)V, (const u64 *)AV,
-				   (u64 *)P, (long long)rows, small, img, ctl);
+		hipLaunchKernelGGL((k_ortho_mfma_prep<8>), dim3(16), dim3(256), 0, s, small, img, ctl);
+		if (pf)
+			hipLaunchKernelGGL((k_ortho_mfma<8, true>), dim3((unsigned)blocks), dim3(MBLOCK), OG<8>::LDS_BYTES, s, (u64 *)V,
+					   (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
+		else
+			hipLaunchKernelGGL((k_ortho_mfma<8, false>), dim3((unsigned)blocks), dim3(MBLOCK), OG<8>::LDS_BYTES, s, (u64 *)V,
+					   (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
 	}
 	return hipGetLastError();
 }

@@ -2334,7 +2334,7 @@ static hipError_t ortho_dispatch(const KernelCfg &c, W *V, const W *AV, W *P, in
 hipError_t launch_orthogonalize(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows,
 				const u64 *small, const DevCtl *ctl, hipStream_t s)
 {
-	if (ortho_mfma_supported(c))
+	if (ortho_mfma_supported(c) && rows >= c.mfma_min_rows)
 		return launch_orthogonalize_mfma(c, V, AV, P, rows, small, ctl, s);
 	if (c.word == 4)
 		return c.mers == 31 ? ortho_dispatch<u32, 31>(c, (u32 *)V, (const u32 *)AV, (u32 *)P, rows, small, ctl, s)

@@ -450,6 +450,7 @@ def test_block_update_on_the_matrix_cores_against_oracle(monkeypatch, n, rows):
                    rng.choice(np.array([1, 2, 3, 2 ** 32 - 1], dtype=np.uint64), size=nz).astype(np.uint32))
     Mo = as_orc(M)
     want = orc.block_lanczos(Mo, n, p, stop_after=4)
+    monkeypatch.setenv("BLZ_MFMA_MIN_ROWS", "0")            # (by default small blocks stay on the vector ALU: launch cost)
     for flag in ("0", "1"):
         monkeypatch.setenv("BLZ_NO_MFMA", flag)
         with blz.Context(p, n) as ctx:
