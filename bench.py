@@ -271,24 +271,54 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
     t0 = time.time()
-    if world == 1:
+    # BLZ_BENCH_SHARE=1 takes the multi-rank set-up path (prepare, cache file, map, upload) with one rank as well, and makes
+    # rank 0 map the file like the others: the way to run that code on a one-GPU box (tests/test_gpu_cli.py)
+    share_test = dist is not None and os.environ.get("BLZ_BENCH_SHARE") == "1"
+    if world == 1 and not share_test:
         ctx.set_matrix(M, right, 0, 1)
     else:
+        import shutil
         import tempfile
-        cache = os.path.join(tempfile.gettempdir(), f"blz_bench_{os.environ.get('MASTER_PORT', '0')}_{args.workload}_{world}.blzcache")
         key = 0x42454E43 ^ (world << 40) ^ info["nnz"]
+        name = f"blz_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}_{args.workload}_{world}.blzcache"
+        status = [None]
+        P = None
         if rank == 0:
-            with blz.Prepared.prepare_for(ctx, M, right, world) as P:
+            try:
+                P = blz.Prepared.prepare_for(ctx, M, right, world)
+                need = 24 * info["nnz"] + 64 * (info["nrows"] + info["ncols"]) + (1 << 20)      # generous bound on the file size
+                dirs = [d for d in ("/dev/shm", tempfile.gettempdir())
+                        if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > need]
+                if not dirs:
+                    raise OSError("no room for the shared set-up file in /dev/shm or the temp directory")
+                cache = os.path.join(dirs[0], name)
                 P.save(cache, key)
-                dist.barrier()
-                ctx.set_matrix_prepared(P, rank)
-        else:
-            dist.barrier()
-            with blz.Prepared.load(cache, key) as P:
-                ctx.set_matrix_prepared(P, rank)
-        dist.barrier()
+                if share_test:
+                    P.close()
+                    P = blz.Prepared.load(cache, key)
+                status = [cache]
+            except Exception as exc:            # the other ranks are waiting: tell them instead of leaving them in a barrier
+                status = [exc]
+        dist.broadcast_object_list(status, src=0)
+        if isinstance(status[0], Exception):
+            leave(1, f"set-up on rank 0 failed: {status[0]!r}")
+        cache = status[0]
+        try:
+            if rank != 0:
+                P = blz.Prepared.load(cache, key)
+            ctx.set_matrix_prepared(P, rank)
+            mine = None
+        except Exception as exc:
+            mine = repr(exc)
+        finally:
+            if P is not None:
+                P.close()
+        errs = [None] * world
+        dist.all_gather_object(errs, mine)
         if rank == 0:
             os.unlink(cache)
+        if any(errs):
+            leave(1, f"matrix upload failed: {[e for e in errs if e]}")
     ctx.init_v()
     ctx.sync()
     t_setup = time.time() - t0

@@ -2,7 +2,7 @@
 ncclAllGather on the exchange stream, the u64 ncclAllReduce of the n x n partials, the event choreography between
 the two streams) -- what mpi/lanczos_modp.c:967-1149 and :1209-1247 do through rank 0.
 
-Every test here needs at least two visible devices and SKIPS below that (the development pool has one GPU per box):
+Every test here but the last needs at least two visible devices and SKIPS below that (the development pool has one GPU per box):
 the moment a multi-GPU box runs the suite, the N > 1 path is validated against the reference's output hashes and
 against the oracle, with no further work.
 """
@@ -155,3 +155,20 @@ def test_bench_under_torch_distributed_run_checks_itself(world):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == world and d["value"] and d["sharded_equals_single_gpu"]["equal"] is True
+
+
+def test_bench_shared_set_up_path_on_one_rank():
+    """The set-up bench.py uses for N > 1 -- rank 0 prepares once, writes the cache file, every rank maps it and uploads
+    its slabs -- run with ONE rank under torch.distributed.run (BLZ_BENCH_SHARE=1 makes rank 0 map the file as the other
+    ranks would) and the RCCL exchange code forced on (BLZ_FORCE_COMM=1), so that a one-GPU box covers everything but the
+    wire.  The line must say that the run equals a plain single-GPU solve."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BLZ_BENCH_SHARE="1", BLZ_FORCE_COMM="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                        "--workload", "tiny", "--steps", "5", "--warmup", "1", "--cpu-seconds", "0", "--ref-iterations", "0"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] and d["sharded_equals_single_gpu"]["equal"] is True
+    assert d["kernels"]["allgather_v"]["launches"] > 0 and d["kernels"]["allreduce"]["launches"] > 0
