@@ -1650,6 +1650,38 @@ __device__ static u64 dev_invmod(u64 a, u64 p)
 	return (u64)t;
 }
 
+/* The same inverse for p = 2^61 - 1 (a prime) as a^(p-2): p - 2 = 2^61 - 3 is 59 ones, a zero and a one in binary, so
+ * 60 squarings and 10 products along the chain 1, 2, 3, 6, 12, 24, 48, 54, 57, 59 (exponents 2^k - 1) do it.  The
+ * inverse mod a prime is unique, so the word is the one the extended Euclid returns; a serial chain of Mersenne
+ * multiplications has no 64-bit division in it (about 36 of them in the Euclid, each some hundred instructions here). */
+__device__ static u64 dev_invmod_mers61(u64 a, const ModP &m)
+{
+	auto sqn = [&](u64 x, int k) {
+		for (int i = 0; i < k; i++)
+			x = mulmod<61>(x, x, m);
+		return x;
+	};
+	const u64 x1 = a;
+	const u64 x2 = mulmod<61>(sqn(x1, 1), x1, m);
+	const u64 x3 = mulmod<61>(sqn(x2, 1), x1, m);
+	const u64 x6 = mulmod<61>(sqn(x3, 3), x3, m);
+	const u64 x12 = mulmod<61>(sqn(x6, 6), x6, m);
+	const u64 x24 = mulmod<61>(sqn(x12, 12), x12, m);
+	const u64 x48 = mulmod<61>(sqn(x24, 24), x24, m);
+	const u64 x54 = mulmod<61>(sqn(x48, 6), x6, m);
+	const u64 x57 = mulmod<61>(sqn(x54, 3), x3, m);
+	const u64 x59 = mulmod<61>(sqn(x57, 2), x2, m);
+	return mulmod<61>(sqn(x59, 2), x1, m);
+}
+
+template <int MERS>
+__device__ static u64 dev_invmod_any(u64 a, const ModP &m)
+{
+	if (MERS == 61)
+		return dev_invmod_mers61(a, m);
+	return dev_invmod(a, m.p);
+}
+
 /*
  * One Gauss-Jordan sweep with the pivot rule of sequential/lanczos_modp.c:351-381 / :393-436: for column
  * j take the first non-zero entry in rows j..n-1; a column without one is skipped (row j is then never
@@ -1790,7 +1822,7 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, 
 			run = mulmod<MERS>(run, S[i], m);
 			Pre[i] = run;
 		}
-		u64 inv = dev_invmod(run, m.p);
+		u64 inv = dev_invmod_any<MERS>(run, m);
 		for (int i = n - 1; i >= 0; i--) {
 			const u64 si = S[i];
 			S[i] = i ? mulmod<MERS>(inv, Pre[i - 1], m) : inv;
@@ -1926,7 +1958,7 @@ k_semi_inverse_reg(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, Mod
 			run = mulmod<MERS>(run, sr, m);
 		pre[r] = run;
 	}
-	u64 inv = dev_invmod(run, m.p), mine = 0;
+	u64 inv = dev_invmod_any<MERS>(run, m), mine = 0;
 #pragma unroll
 	for (int r = G - 1; r >= 0; r--) {
 		const u64 sr = shfl64(s, r << LG);
