@@ -48,6 +48,7 @@ struct DevCsr {
 	int panel_rows = 0;
 	bool xcd_ranges = false;	/* k_spmv / k_spmv_dot walk per-XCD row ranges (set when the renumbering found locality) */
 	long long xr_rows[9] = { 0 };	/* XCD x takes rows [xr_rows[x], xr_rows[x+1]); xr_rows[0] < 0: equal stripes */
+	int st_deep = 1;		/* 8 gathers in flight per lane where the kernel has that form (else 4): off for rows of a few entries */
 	int st_interleave = 0;		/* 1: tiles round-robin over the whole grid instead of per-XCD ranges */
 	long long st_tiles[9] = { 0 };	/* XCD x takes tiles [st_tiles[x], st_tiles[x+1]): contiguous, nnz-balanced */
 };

@@ -1154,7 +1154,12 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D)
 	}
 	const int GPW = 64 / G, NS = (D.val && !D.palette) ? 2 : 1;
 	const double avg = D.kept_mean >= 0.0 ? D.kept_mean : (double)D.nnz / (double)D.rows;
-	int per_cu = c.spmv_blocks_per_cu > 0 ? c.spmv_blocks_per_cu : ((avg >= 12.0 && G < 16) ? (D.uneven ? 6 : 4) : 8);
+	/* Rows of a few entries (relat9 shape, 3.15 per row, profiles/r02_exp_staged_sweep_relat9.txt): a batch of 8 gathers
+	 * per lane is mostly switched-off slots, and 16 wavefronts per CU with the larger window beat 32 with the smaller one
+	 * (672 -> 622 us in the iteration; 4 per CU x U = 4: 623 us, 8 x 4: 691, 4 x 8: 772, 8 x 8: 739 in the sweep). */
+	const bool few = avg < 6.0 && G < 16;
+	D.st_deep = !few;
+	int per_cu = c.spmv_blocks_per_cu > 0 ? c.spmv_blocks_per_cu : (((avg >= 12.0 || few) && G < 16) ? (D.uneven && !few ? 6 : 4) : 8);
 	/* LDS: 4 wavefronts x 2 buffers x capw entries x 4 B per block (x NS streams); 160 KB per CU */
 	int capw = (per_cu <= 4 ? 1024 : 512) / NS;
 	if (const char *e = getenv("BLZ_STAGE_CAPW"))
@@ -1210,7 +1215,7 @@ static void staged_launch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y,
 	const size_t lds = (size_t)(BLOCK / 64) * 2 * A.st_ns * A.st_capw * sizeof(u32);
 	/* gathers in flight per lane: 8 where a wavefront holds few lane groups (G >= 16) or the registers allow (the
 	 * plain form at G = 8), else 4; BLZ_STAGE_U overrides between the two where both exist */
-	bool deep = G >= 16 || (G == 8 && !DOT);
+	bool deep = G >= 16 || (G == 8 && !DOT && A.st_deep);
 	if (const char *e = getenv("BLZ_STAGE_U"))
 		deep = atoi(e) >= 8;
 #define STAGED_GO(UU)                                                                                                   \
