@@ -113,19 +113,28 @@ k_ortho_mfma_prep(const u64 *__restrict__ small, unsigned char *__restrict__ img
 		const int E = 64 * kc + 16 * (ln >> 4) + j;
 		B[idx] = (signed char)signed_digit(rot61(coefficient<NT>(small, ch, E >> 3, ln & 15), 8 * (E & 7)), dg);
 	}
-	if (blockIdx.x != 0)
-		return;
-	/* accumulator start: 128 * (sum over K' of B_t[.][col]) + 2^24 */
-	for (int e = t; e < G::NCH * G::ND * 16; e += 256) {
+	/* accumulator start: 128 * (sum over K' of B_t[.][col]) + 2^24; the entries are dealt to the workgroups, the K' of one
+	 * entry to the threads (one thread per entry took 7 us in one workgroup) */
+	constexpr int NE = G::NCH * G::ND * 16;
+	__shared__ int part[4];
+	const int per = (NE + (int)gridDim.x - 1) / (int)gridDim.x;
+	for (int q = 0; q < per; q++) {
+		const int e = blockIdx.x * per + q;		/* uniform over the workgroup */
+		if (e >= NE)
+			break;
 		const int col = e & 15, dg = (e >> 4) & 7, ch = e >> 7;
-		const int words = ch == 0 ? G::KS1 * 8 : G::KS2 * 8;
+		const int nk = (ch == 0 ? G::KS1 : G::KS2) * 64;
 		int sum = 0;
-		for (int kk = 0; kk < words; kk++) {
-			const u64 x = coefficient<NT>(small, ch, kk, col);
-			for (int a = 0; a < 8; a++)
-				sum += signed_digit(rot61(x, 8 * a), dg);
-		}
-		init[e] = 128 * sum + (1 << 24);
+		for (int kp = t; kp < nk; kp += 256)
+			sum += signed_digit(rot61(coefficient<NT>(small, ch, kp >> 3, col), 8 * (kp & 7)), dg);
+		for (int off = 32; off; off >>= 1)
+			sum += __shfl_xor(sum, off, 64);
+		if ((t & 63) == 0)
+			part[t >> 6] = sum;
+		__syncthreads();
+		if (t == 0)
+			init[e] = 128 * (part[0] + part[1] + part[2] + part[3]) + (1 << 24);
+		__syncthreads();
 	}
 }
 
