@@ -34,7 +34,6 @@
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-#define MBLOCK 256
 
 template <int NT>
 struct OG {
@@ -46,8 +45,12 @@ struct OG {
 	static constexpr bool STAGED = NT == 16;
 	static constexpr bool PREFETCH = NT == 16;	/* load the next tile during the arithmetic: n = 8 lost by it (150 vs 124 us) */
 	static constexpr int RSTR = NT * 8 + 16;
-	static constexpr size_t STAGE_BYTES = STAGED ? (size_t)2 * 16 * RSTR : 0;
-	static constexpr size_t LDS_BYTES = IMG_BYTES + (MBLOCK / 64) * STAGE_BYTES;
+	static constexpr size_t STAGE_BYTES = STAGED ? (size_t)3 * 16 * RSTR : 0;	/* v, p, Av */
+	static constexpr size_t lds_bytes(int threads) { return IMG_BYTES + (size_t)(threads / 64) * STAGE_BYTES; }
+	/* threads per workgroup (BLZ_MFMA_BLOCK takes fewer).  n = 16: ONE workgroup of 16 wavefronts per CU next to the 49 KB image
+	 * and their 108 KB of staging areas -- 1.77 ms with 2 x 4 wavefronts, 1.56 with 12, 1.49 with 16 on the config-5 quarter
+	 * shape, which is what a bare streaming kernel with this traffic reaches.  n = 8: 256 (five workgroups per CU). */
+	static constexpr int THREADS = NT == 16 ? 1024 : 256;
 };
 
 /* weight of digit sum s in the folded result: 2^(8 s mod 61), applied as a 32-bit multiplier into L (shift < 32) or H */
@@ -180,7 +183,8 @@ template <int NT>
 struct OrthoTile {
 	static constexpr int NLD = NT / 8;		/* 16-byte loads per lane and block: 16 rows x 8 NT bytes / 1 KB */
 	v4i a[2 * NLD];
-	u64 b1[4], b2[4];
+	v4i c[NLD];		/* staged form: the rows of Av, as they lie */
+	u64 b1[4], b2[4];	/* direct form: the terms that are not products */
 };
 
 template <int NT>
@@ -198,7 +202,11 @@ MODP_DEV void ortho_tile_load(OrthoTile<NT> &R, const u64 *V, const u64 *AV, con
 		const size_t at = (size_t)rr * ROWB + (o % ROWB);
 		R.a[q] = *(const v4i *)((const unsigned char *)V + at);
 		R.a[NLD + q] = *(const v4i *)((const unsigned char *)Pb + at);
+		if (OG<NT>::STAGED)
+			R.c[q] = *(const v4i *)((const unsigned char *)AV + at);
 	}
+	if (OG<NT>::STAGED)
+		return;		/* the other terms come out of the staged rows */
 #pragma unroll
 	for (int reg = 0; reg < 4; reg++) {
 		long long rr = r0 + 4 * h + reg;
@@ -215,7 +223,7 @@ MODP_DEV void ortho_tile_load(OrthoTile<NT> &R, const u64 *V, const u64 *AV, con
 }
 
 template <int NT, bool PF>
-__global__ void __launch_bounds__(MBLOCK)
+__global__ void __launch_bounds__(OG<NT>::THREADS)
 k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ Pb, long long rows,
 	     const u64 *__restrict__ small, const unsigned char *__restrict__ img, const DevCtl *__restrict__ ctl)
 {
@@ -228,7 +236,7 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 	{
 		const uint4 *src = (const uint4 *)img;
 		uint4 *dst = (uint4 *)lds;
-		for (int i = threadIdx.x; i < (int)(G::IMG_BYTES / 16); i += MBLOCK)
+		for (int i = threadIdx.x; i < (int)(G::IMG_BYTES / 16); i += (int)blockDim.x)
 			dst[i] = src[i];
 	}
 	__syncthreads();
@@ -242,7 +250,7 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 	/* this wavefront's staging area: the tile's rows of v, then of p, each row padded by 16 bytes so that the 16 rows a
 	 * fragment read touches fall on different banks */
 	unsigned char *stage = lds + G::IMG_BYTES + (threadIdx.x >> 6) * G::STAGE_BYTES;
-	const long long wave = ((long long)blockIdx.x * MBLOCK + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * MBLOCK) >> 6;
+	const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
 	const long long ntiles = (rows + 15) >> 4;
 	/* which output this lane's tile column is, and its selector d */
 	const int jout = NT == 16 ? col : (col & 7);
@@ -265,6 +273,7 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 				const int at = (o / ROWB) * G::RSTR + (o % ROWB);
 				*(v4i *)(stage + at) = R.a[q];
 				*(v4i *)(stage + 16 * G::RSTR + at) = R.a[NLD + q];
+				*(v4i *)(stage + 32 * G::RSTR + at) = R.c[q];
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
@@ -284,10 +293,12 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 		for (int q = 0; q < G::KS1; q++)
 			A[q] ^= (v4i){ (int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080 };
 		u64 base1[4], base2[4];
+		if (!G::STAGED) {
 #pragma unroll
-		for (int reg = 0; reg < 4; reg++) {
-			base1[reg] = R.b1[reg];
-			base2[reg] = R.b2[reg];
+			for (int reg = 0; reg < 4; reg++) {
+				base1[reg] = R.b1[reg];
+				base2[reg] = R.b2[reg];
+			}
 		}
 		/* the next tile's loads fly during this tile's arithmetic */
 		if (PF && tile + nwaves < ntiles)
@@ -325,6 +336,48 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 			/* keep the digit sums sequential: without this the compiler hoists all the fragment reads (and spills) */
 			asm volatile("" ::: "memory");
 		}
+		if (G::STAGED) {
+			/* the terms that are not products come out of the staged rows (they are still there; 16 registers less
+			 * across the arithmetic); then results -> LDS in the accumulator layout (row 4 h + reg, column col), and out
+			 * as the rows lie: 16 bytes per lane, whole lines per instruction */
+#pragma unroll
+			for (int reg = 0; reg < 4; reg++) {
+				const int at = (4 * h + reg) * G::RSTR + 8 * col;
+				base1[reg] = *(const u64 *)(stage + (dj ? 32 * G::RSTR : 0) + at);
+				base2[reg] = dj ? 0 : *(const u64 *)(stage + 16 * G::RSTR + at);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int reg = 0; reg < 4; reg++) {
+				const int at = (4 * h + reg) * G::RSTR + 8 * col;
+				u64 x = fold61(L1[reg], H1[reg]);
+				x = addmod(x, fconst, PR);
+				x = addmod(x, base1[reg], PR);
+				u64 y = fold61(L2[reg], H2[reg]);
+				y = addmod(y, fconst, PR);
+				y = addmod(y, base2[reg], PR);
+				*(u64 *)(stage + at) = x;
+				*(u64 *)(stage + 16 * G::RSTR + at) = y;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int q = 0; q < NLD; q++) {
+				const int o = 16 * lane + 1024 * q;
+				const int at = (o / ROWB) * G::RSTR + (o % ROWB);
+				const v4i xv = *(const v4i *)(stage + at), yv = *(const v4i *)(stage + 16 * G::RSTR + at);
+				const long long rr = r0 + o / ROWB;
+				if (rr < rows) {
+					const size_t to = (size_t)rr * ROWB + (o % ROWB);
+					*(v4i *)((unsigned char *)V + to) = xv;
+					*(v4i *)((unsigned char *)Pb + to) = yv;
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			continue;
+		}
 #pragma unroll
 		for (int reg = 0; reg < 4; reg++) {
 			const long long rr = r0 + 4 * h + reg;
@@ -356,27 +409,39 @@ bool ortho_mfma_supported(const KernelCfg &c)
 	return c.mfma && c.mfma_img && c.word == 8 && c.mers == 61 && (c.n == 8 || c.n == 16);
 }
 
-/* workgroups of k_ortho_mfma<NT> one CU holds (registers and the LDS image decide), asked once per device */
+/* threads per workgroup and workgroups per CU of k_ortho_mfma<NT> (registers and the LDS image decide), asked once per device */
 template <int NT>
-static int ortho_mfma_blocks_per_cu(void)
+static void ortho_mfma_shape(int *threads, int *per_cu)
 {
-	static int per_cu[64] = { 0 };
+	static int cached_t[64] = { 0 }, cached_k[64] = { 0 };
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	if (dev >= 0 && dev < 64 && per_cu[dev] > 0)
-		return per_cu[dev];
+	if (dev >= 0 && dev < 64 && cached_k[dev] > 0) {
+		*threads = cached_t[dev];
+		*per_cu = cached_k[dev];
+		return;
+	}
+	int t = OG<NT>::THREADS;
+	if (const char *e = getenv("BLZ_MFMA_BLOCK"))	/* experiments */
+		if (atoi(e) >= 64 && atoi(e) <= OG<NT>::THREADS && atoi(e) % 64 == 0)
+			t = atoi(e);
+	const void *fn = (const void *)k_ortho_mfma<NT, OG<NT>::PREFETCH>;
+	const size_t lds = OG<NT>::lds_bytes(t);
 	int k = 0;
 	/* more than 64 KB of dynamic LDS needs the attribute, once per DEVICE (several contexts of one process) */
-	if (OG<NT>::LDS_BYTES > 65536)
-		(void)hipFuncSetAttribute((const void *)k_ortho_mfma<NT, OG<NT>::PREFETCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OG<NT>::LDS_BYTES);
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, (const void *)k_ortho_mfma<NT, OG<NT>::PREFETCH>, MBLOCK, OG<NT>::LDS_BYTES) != hipSuccess || k < 1)
+	if (lds > 65536)
+		(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, fn, t, lds) != hipSuccess || k < 1)
 		k = 1;
 	const char *e = getenv("BLZ_MFMA_PER_CU");	/* experiments */
 	if (e && atoi(e) > 0 && atoi(e) < k)
 		k = atoi(e);
-	if (dev >= 0 && dev < 64)
-		per_cu[dev] = k;
-	return k;
+	if (dev >= 0 && dev < 64) {
+		cached_t[dev] = t;
+		cached_k[dev] = k;
+	}
+	*threads = t;
+	*per_cu = k;
 }
 
 hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows, const u64 *small,
@@ -384,30 +449,25 @@ hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV
 {
 	if (rows <= 0)
 		return hipSuccess;
-	const long long ntiles = (rows + 15) / 16;
-	long long blocks = (ntiles + MBLOCK / 64 - 1) / (MBLOCK / 64);
+	int threads = 0, per_cu = 0;
+	if (c.n == 16)
+		ortho_mfma_shape<16>(&threads, &per_cu);
+	else
+		ortho_mfma_shape<8>(&threads, &per_cu);
+	const long long ntiles = (rows + 15) / 16, wpb = threads / 64;
+	long long blocks = (ntiles + wpb - 1) / wpb;
 	/* the B image sits in LDS: 49 KB at n = 16, 16 KB at n = 8; a persistent grid of as many workgroups as fit */
-	const long long cap = (long long)c.num_cu * (c.n == 16 ? ortho_mfma_blocks_per_cu<16>() : ortho_mfma_blocks_per_cu<8>());
+	const long long cap = (long long)c.num_cu * per_cu;
 	blocks = blocks > cap ? cap : blocks;
 	unsigned char *img = (unsigned char *)c.mfma_img;
-	static const char *pfe = getenv("BLZ_MFMA_PREFETCH");		/* experiments: 0 / 1 overrides the measured choice */
-	const bool pf = pfe ? atoi(pfe) != 0 : (c.n == 16 ? OG<16>::PREFETCH : OG<8>::PREFETCH);
 	if (c.n == 16) {
 		hipLaunchKernelGGL((k_ortho_mfma_prep<16>), dim3(32), dim3(256), 0, s, small, img, ctl);
-		if (pf)
-			hipLaunchKernelGGL((k_ortho_mfma<16, true>), dim3((unsigned)blocks), dim3(MBLOCK), OG<16>::LDS_BYTES, s, (u64 *)V,
-					   (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
-		else
-			hipLaunchKernelGGL((k_ortho_mfma<16, false>), dim3((unsigned)blocks), dim3(MBLOCK), OG<16>::LDS_BYTES, s, (u64 *)V,
-					   (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
+		hipLaunchKernelGGL((k_ortho_mfma<16, OG<16>::PREFETCH>), dim3((unsigned)blocks), dim3(threads), OG<16>::lds_bytes(threads), s,
+				   (u64 *)V, (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
 	} else {
 		hipLaunchKernelGGL((k_ortho_mfma_prep<8>), dim3(16), dim3(256), 0, s, small, img, ctl);
-		if (pf)
-			hipLaunchKernelGGL((k_ortho_mfma<8, true>), dim3((unsigned)blocks), dim3(MBLOCK), OG<8>::LDS_BYTES, s, (u64 *)V,
-					   (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
-		else
-			hipLaunchKernelGGL((k_ortho_mfma<8, false>), dim3((unsigned)blocks), dim3(MBLOCK), OG<8>::LDS_BYTES, s, (u64 *)V,
-					   (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
+		hipLaunchKernelGGL((k_ortho_mfma<8, OG<8>::PREFETCH>), dim3((unsigned)blocks), dim3(threads), OG<8>::lds_bytes(threads), s,
+				   (u64 *)V, (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
 	}
 	return hipGetLastError();
 }
