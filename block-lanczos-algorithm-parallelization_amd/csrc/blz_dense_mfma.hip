@@ -35,22 +35,22 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 
-template <int NT>
+template <int NT, bool ST = true>
 struct OG {
 	static constexpr int KS1 = NT == 16 ? 4 : 2, KS2 = NT == 16 ? 2 : 0, KS = KS1 + KS2, NCH = NT == 16 ? 2 : 1;
 	static constexpr int ND = 8;		/* digit positions of a multiplier */
 	static constexpr size_t B_BYTES = (size_t)KS * ND * 64 * 16, INIT_BYTES = (size_t)NCH * ND * 16 * 4;
 	static constexpr size_t IMG_BYTES = B_BYTES + INIT_BYTES;
 	/* n = 16 stages the rows through LDS; per wavefront 16 rows of v and 16 of p, row stride = row bytes + 16 (bank spread) */
-	static constexpr bool STAGED = NT == 16;
-	static constexpr bool PREFETCH = NT == 16;	/* load the next tile during the arithmetic: n = 8 lost by it (150 vs 124 us) */
+	static constexpr bool STAGED = ST;
+	static constexpr bool PREFETCH = ST;		/* load the next tile during the arithmetic: the direct form lost by it (150 vs 124 us) */
 	static constexpr int RSTR = NT * 8 + 16;
 	static constexpr size_t STAGE_BYTES = STAGED ? (size_t)3 * 16 * RSTR : 0;	/* v, p, Av */
 	static constexpr size_t lds_bytes(int threads) { return IMG_BYTES + (size_t)(threads / 64) * STAGE_BYTES; }
 	/* threads per workgroup (BLZ_MFMA_BLOCK takes fewer).  n = 16: ONE workgroup of 16 wavefronts per CU next to the 49 KB image
 	 * and their 108 KB of staging areas -- 1.77 ms with 2 x 4 wavefronts, 1.56 with 12, 1.49 with 16 on the config-5 quarter
 	 * shape, which is what a bare streaming kernel with this traffic reaches.  n = 8: 256 (five workgroups per CU). */
-	static constexpr int THREADS = NT == 16 ? 1024 : 256;
+	static constexpr int THREADS = !ST ? 256 : (NT == 16 ? 1024 : 768);
 };
 
 /* weight of digit sum s in the folded result: 2^(8 s mod 61), applied as a 32-bit multiplier into L (shift < 32) or H */
@@ -174,11 +174,13 @@ MODP_DEV u64 fold61(u64 L, u64 H)
 
 /* What a wavefront holds of one 16-row tile between the loads and their use: the rows of v and p, and the terms that are
  * not products, already in the accumulator layout (row 4 h + reg, column col).
- * n = 16 (128-byte rows): the rows are loaded as they lie in memory (lane l has bytes 16 l .. 16 l + 15 of the tile's first
- * KB, then of the second, so every load instruction covers whole lines) and pass through LDS to become A fragments: loading
- * fragments directly makes each quarter-wavefront touch 16 lines for 16 bytes each, four times per row, and the kernel
- * got SLOWER with more wavefronts per CU (2.32 ms at 12, 1.95 ms at 8; staged 1.81 ms).
- * n = 8 (64-byte rows): a fragment load covers 1 KB of consecutive rows anyway; staging cost more than it gave (147 vs 124 us). */
+ * Staged form (n = 16, 128-byte rows): the rows of v, p AND Av are loaded as they lie in memory (lane l has bytes 16 l ..
+ * 16 l + 15 of the tile's first KB, then of the second, so every load instruction covers whole lines), pass through a
+ * padded per-wavefront LDS area to become A fragments and accumulator-layout terms, and the results go back the same way
+ * (16-byte stores).  Loading fragments directly makes each quarter-wavefront touch 16 lines for 16 bytes each, four times
+ * per row, and that kernel got SLOWER with more wavefronts per CU (2.32 ms at 12, 1.95 ms at 8); this one gets faster
+ * (1.77 ms at 8, 1.40 ms at 16 = the rate of a bare streaming kernel with the same traffic).
+ * Direct form (n = 8, 64-byte rows): a fragment load covers 1 KB of consecutive rows anyway; staging gives nothing there. */
 template <int NT>
 struct OrthoTile {
 	static constexpr int NLD = NT / 8;		/* 16-byte loads per lane and block: 16 rows x 8 NT bytes / 1 KB */
@@ -187,7 +189,7 @@ struct OrthoTile {
 	u64 b1[4], b2[4];	/* direct form: the terms that are not products */
 };
 
-template <int NT>
+template <int NT, bool ST>
 MODP_DEV void ortho_tile_load(OrthoTile<NT> &R, const u64 *V, const u64 *AV, const u64 *Pb, long long rows, long long tile,
 			      int lane, int h, int jout, bool is_p, bool dj)
 {
@@ -196,16 +198,16 @@ MODP_DEV void ortho_tile_load(OrthoTile<NT> &R, const u64 *V, const u64 *AV, con
 #pragma unroll
 	for (int q = 0; q < NLD; q++) {
 		/* staged: byte o of the tile; direct: row m = lane & 15, bytes 16 h .. of its 64-byte part q */
-		const int o = OG<NT>::STAGED ? 16 * lane + 1024 * q : (lane & 15) * ROWB + 64 * q + 16 * h;
+		const int o = ST ? 16 * lane + 1024 * q : (lane & 15) * ROWB + 64 * q + 16 * h;
 		long long rr = r0 + o / ROWB;
 		rr = rr < rows ? rr : rows - 1;		/* rows past the end: any valid address, the results are not stored */
 		const size_t at = (size_t)rr * ROWB + (o % ROWB);
 		R.a[q] = *(const v4i *)((const unsigned char *)V + at);
 		R.a[NLD + q] = *(const v4i *)((const unsigned char *)Pb + at);
-		if (OG<NT>::STAGED)
+		if (ST)
 			R.c[q] = *(const v4i *)((const unsigned char *)AV + at);
 	}
-	if (OG<NT>::STAGED)
+	if (ST)
 		return;		/* the other terms come out of the staged rows */
 #pragma unroll
 	for (int reg = 0; reg < 4; reg++) {
@@ -222,14 +224,15 @@ MODP_DEV void ortho_tile_load(OrthoTile<NT> &R, const u64 *V, const u64 *AV, con
 	}
 }
 
-template <int NT, bool PF>
-__global__ void __launch_bounds__(OG<NT>::THREADS)
+template <int NT, bool ST>
+__global__ void __launch_bounds__((OG<NT, ST>::THREADS))
 k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ Pb, long long rows,
 	     const u64 *__restrict__ small, const unsigned char *__restrict__ img, const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
-	using G = OG<NT>;
+	using G = OG<NT, ST>;
+	constexpr bool PF = G::PREFETCH;
 	constexpr int NN = NT * NT;
 	constexpr int ROWB = NT * 8, NLD = OrthoTile<NT>::NLD;
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -258,11 +261,11 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 	const bool dj = small[3 * NN + jout] != 0;
 	OrthoTile<NT> R;
 	if (PF && wave < ntiles)
-		ortho_tile_load<NT>(R, V, AV, Pb, rows, wave, lane, h, jout, is_p, dj);
+		ortho_tile_load<NT, ST>(R, V, AV, Pb, rows, wave, lane, h, jout, is_p, dj);
 	for (long long tile = wave; tile < ntiles; tile += nwaves) {
 		const long long r0 = tile << 4;
 		if (!PF)
-			ortho_tile_load<NT>(R, V, AV, Pb, rows, tile, lane, h, jout, is_p, dj);
+			ortho_tile_load<NT, ST>(R, V, AV, Pb, rows, tile, lane, h, jout, is_p, dj);
 		/* A fragments: row m, 16 bytes per K-step, biased to signed */
 		v4i A[G::KS1];
 		if (G::STAGED) {
@@ -302,7 +305,7 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 		}
 		/* the next tile's loads fly during this tile's arithmetic */
 		if (PF && tile + nwaves < ntiles)
-			ortho_tile_load<NT>(R, V, AV, Pb, rows, tile + nwaves, lane, h, jout, is_p, dj);
+			ortho_tile_load<NT, ST>(R, V, AV, Pb, rows, tile + nwaves, lane, h, jout, is_p, dj);
 		u64 L1[4] = { 0, 0, 0, 0 }, H1[4] = { 0, 0, 0, 0 }, L2[4] = { 0, 0, 0, 0 }, H2[4] = { 0, 0, 0, 0 };
 #pragma unroll
 		for (int s = 0; s < G::ND; s++) {
@@ -343,8 +346,16 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 #pragma unroll
 			for (int reg = 0; reg < 4; reg++) {
 				const int at = (4 * h + reg) * G::RSTR + 8 * col;
-				base1[reg] = *(const u64 *)(stage + (dj ? 32 * G::RSTR : 0) + at);
-				base2[reg] = dj ? 0 : *(const u64 *)(stage + 16 * G::RSTR + at);
+				if (NT == 16) {
+					base1[reg] = *(const u64 *)(stage + (dj ? 32 * G::RSTR : 0) + at);
+					base2[reg] = dj ? 0 : *(const u64 *)(stage + 16 * G::RSTR + at);
+				} else {
+					/* columns 0..7 of the tile are v', 8..15 p' */
+					const int at8 = (4 * h + reg) * G::RSTR + 8 * jout;
+					base1[reg] = is_p ? (dj ? 0 : *(const u64 *)(stage + 16 * G::RSTR + at8))
+							  : *(const u64 *)(stage + (dj ? 32 * G::RSTR : 0) + at8);
+					base2[reg] = 0;
+				}
 			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
@@ -354,11 +365,15 @@ k_ortho_mfma(u64 *__restrict__ V, const u64 *__restrict__ AV, u64 *__restrict__ 
 				u64 x = fold61(L1[reg], H1[reg]);
 				x = addmod(x, fconst, PR);
 				x = addmod(x, base1[reg], PR);
-				u64 y = fold61(L2[reg], H2[reg]);
-				y = addmod(y, fconst, PR);
-				y = addmod(y, base2[reg], PR);
-				*(u64 *)(stage + at) = x;
-				*(u64 *)(stage + 16 * G::RSTR + at) = y;
+				if (NT == 16) {
+					u64 y = fold61(L2[reg], H2[reg]);
+					y = addmod(y, fconst, PR);
+					y = addmod(y, base2[reg], PR);
+					*(u64 *)(stage + at) = x;
+					*(u64 *)(stage + 16 * G::RSTR + at) = y;
+				} else {
+					*(u64 *)(stage + (is_p ? 16 * G::RSTR : 0) + (4 * h + reg) * G::RSTR + 8 * jout) = x;
+				}
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
@@ -409,10 +424,11 @@ bool ortho_mfma_supported(const KernelCfg &c)
 	return c.mfma && c.mfma_img && c.word == 8 && c.mers == 61 && (c.n == 8 || c.n == 16);
 }
 
-/* threads per workgroup and workgroups per CU of k_ortho_mfma<NT> (registers and the LDS image decide), asked once per device */
-template <int NT>
+/* threads per workgroup and workgroups per CU of k_ortho_mfma<NT, ST> (registers and LDS decide), asked once per device */
+template <int NT, bool ST>
 static void ortho_mfma_shape(int *threads, int *per_cu)
 {
+	using G = OG<NT, ST>;
 	static int cached_t[64] = { 0 }, cached_k[64] = { 0 };
 	int dev = 0;
 	(void)hipGetDevice(&dev);
@@ -421,12 +437,12 @@ static void ortho_mfma_shape(int *threads, int *per_cu)
 		*per_cu = cached_k[dev];
 		return;
 	}
-	int t = OG<NT>::THREADS;
+	int t = G::THREADS;
 	if (const char *e = getenv("BLZ_MFMA_BLOCK"))	/* experiments */
-		if (atoi(e) >= 64 && atoi(e) <= OG<NT>::THREADS && atoi(e) % 64 == 0)
+		if (atoi(e) >= 64 && atoi(e) <= G::THREADS && atoi(e) % 64 == 0)
 			t = atoi(e);
-	const void *fn = (const void *)k_ortho_mfma<NT, OG<NT>::PREFETCH>;
-	const size_t lds = OG<NT>::lds_bytes(t);
+	const void *fn = (const void *)k_ortho_mfma<NT, ST>;
+	const size_t lds = G::lds_bytes(t);
 	int k = 0;
 	/* more than 64 KB of dynamic LDS needs the attribute, once per DEVICE (several contexts of one process) */
 	if (lds > 65536)
@@ -444,31 +460,39 @@ static void ortho_mfma_shape(int *threads, int *per_cu)
 	*per_cu = k;
 }
 
+template <int NT, bool ST>
+static void ortho_mfma_go(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows, const u64 *small, const DevCtl *ctl,
+			  hipStream_t s)
+{
+	int threads = 0, per_cu = 0;
+	ortho_mfma_shape<NT, ST>(&threads, &per_cu);
+	const long long ntiles = (rows + 15) / 16, wpb = threads / 64;
+	long long blocks = (ntiles + wpb - 1) / wpb;
+	/* a persistent grid of as many workgroups as fit beside the B image in LDS (49 KB at n = 16, 16 KB at n = 8) */
+	const long long cap = (long long)c.num_cu * per_cu;
+	blocks = blocks > cap ? cap : blocks;
+	unsigned char *img = (unsigned char *)c.mfma_img;
+	hipLaunchKernelGGL((k_ortho_mfma_prep<NT>), dim3(2 * NT), dim3(256), 0, s, small, img, ctl);
+	const size_t lds = OG<NT, ST>::lds_bytes(threads);
+	hipLaunchKernelGGL((k_ortho_mfma<NT, ST>), dim3((unsigned)blocks), dim3(threads), lds, s, (u64 *)V, (const u64 *)AV, (u64 *)P,
+			   (long long)rows, small, img, ctl);
+}
+
 hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows, const u64 *small,
 				     const DevCtl *ctl, hipStream_t s)
 {
 	if (rows <= 0)
 		return hipSuccess;
-	int threads = 0, per_cu = 0;
+	/* n = 8 (64-byte rows: a fragment load covers 1 KB of consecutive rows anyway) loads fragments straight from HBM:
+	 * the staged form is no faster there (115.6 / 116.0 against 113.9 / 114.6 us on the GL7d19 shape); BLZ_MFMA_STAGE8=1
+	 * takes it for A/B */
+	static const char *se = getenv("BLZ_MFMA_STAGE8");
 	if (c.n == 16)
-		ortho_mfma_shape<16>(&threads, &per_cu);
+		ortho_mfma_go<16, true>(c, V, AV, P, rows, small, ctl, s);
+	else if (se && se[0] == '1')
+		ortho_mfma_go<8, true>(c, V, AV, P, rows, small, ctl, s);
 	else
-		ortho_mfma_shape<8>(&threads, &per_cu);
-	const long long ntiles = (rows + 15) / 16, wpb = threads / 64;
-	long long blocks = (ntiles + wpb - 1) / wpb;
-	/* the B image sits in LDS: 49 KB at n = 16, 16 KB at n = 8; a persistent grid of as many workgroups as fit */
-	const long long cap = (long long)c.num_cu * per_cu;
-	blocks = blocks > cap ? cap : blocks;
-	unsigned char *img = (unsigned char *)c.mfma_img;
-	if (c.n == 16) {
-		hipLaunchKernelGGL((k_ortho_mfma_prep<16>), dim3(32), dim3(256), 0, s, small, img, ctl);
-		hipLaunchKernelGGL((k_ortho_mfma<16, OG<16>::PREFETCH>), dim3((unsigned)blocks), dim3(threads), OG<16>::lds_bytes(threads), s,
-				   (u64 *)V, (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
-	} else {
-		hipLaunchKernelGGL((k_ortho_mfma_prep<8>), dim3(16), dim3(256), 0, s, small, img, ctl);
-		hipLaunchKernelGGL((k_ortho_mfma<8, OG<8>::PREFETCH>), dim3((unsigned)blocks), dim3(threads), OG<8>::lds_bytes(threads), s,
-				   (u64 *)V, (const u64 *)AV, (u64 *)P, (long long)rows, small, img, ctl);
-	}
+		ortho_mfma_go<8, false>(c, V, AV, P, rows, small, ctl, s);
 	return hipGetLastError();
 }
 
