@@ -30,6 +30,7 @@
 #include "blz_kernels.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -540,6 +541,24 @@ MODP_DEV void digit_fragments(const u64 *x, v4i *frag)
 	}
 }
 
+/* the same for two digits only: digits 2 * pr and 2 * pr + 1 (pr = 0..3) of the 16 words -> out[0], out[1].  Eight calls
+ * cost the perms of one digit_fragments(); the n = 16 inner products use it to hold two fragments of the left operand at
+ * a time instead of eight (24 registers less: two wavefronts per SIMD instead of one). */
+template <int PR_>
+MODP_DEV void digit_fragment_pair(const u64 *x, v4i *out)
+{
+	constexpr int half = PR_ >> 1, hi = PR_ & 1;	/* 32-bit half of the word; bytes 0,1 or 2,3 of it */
+#pragma unroll
+	for (int d = 0; d < 4; d++) {
+		const u32 w0 = (u32)(x[4 * d + 0] >> (32 * half)), w1 = (u32)(x[4 * d + 1] >> (32 * half));
+		const u32 w2 = (u32)(x[4 * d + 2] >> (32 * half)), w3 = (u32)(x[4 * d + 3] >> (32 * half));
+		const u32 t01 = __builtin_amdgcn_perm(w1, w0, hi ? 0x07030602u : 0x05010400u);
+		const u32 t23 = __builtin_amdgcn_perm(w3, w2, hi ? 0x07030602u : 0x05010400u);
+		out[0][d] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+		out[1][d] = (int)(__builtin_amdgcn_perm(t23, t01, 0x07060302u) ^ 0x80808080u);
+	}
+}
+
 MODP_DEV u64 shfl64m(u64 x, int src)
 {
 	const u32 lo = (u32)__shfl((int)(u32)x, src, 64), hi = (u32)__shfl((int)(u32)(x >> 32), src, 64);
@@ -552,7 +571,7 @@ MODP_DEV u64 fold_partial61(u64 s)	/* s < 2^64 -> < 2^62, congruent mod 2^61 - 1
 }
 
 template <int NT>
-__global__ void __launch_bounds__(DBLOCK)
+__global__ void __launch_bounds__(DBLOCK, 2)	/* two wavefronts per SIMD: 256 registers (accumulators included) */
 k_block_dot_mfma(const u64 *__restrict__ V, const u64 *__restrict__ AV, long long rows, u64 *__restrict__ partial,
 		 const DevCtl *__restrict__ ctl)
 {
@@ -633,20 +652,38 @@ k_block_dot_mfma(const u64 *__restrict__ V, const u64 *__restrict__ AV, long lon
 			if (NT == 16)
 				cs1 = fold_partial61(cs1 + xa[q] + xa[q + 1] + xa[q + 2] + xa[q + 3]);
 		}
-		v4i fv[8], fa[8];
-		digit_fragments(xv, fv);
-		if (NT == 16)
+		if (NT == 16) {
+			/* Av^T Av and V^T Av share the right operand; the left one's fragments are made two digits at a time */
+			v4i fa[8];
 			digit_fragments(xa, fa);
 #pragma unroll
-		for (int a = 0; a < 8; a++) {
+			for (int a = 0; a < 8; a++) {
 #pragma unroll
-			for (int b = 0; b < 8; b++) {
-				if (NT == 16) {
-					acc[0][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv[a], fa[b], acc[0][a + b], 0, 0, 0);
+				for (int b = 0; b < 8; b++)
 					acc[NP - 1][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fa[b], acc[NP - 1][a + b], 0, 0, 0);
-				} else {
-					acc[0][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv[a], fv[b], acc[0][a + b], 0, 0, 0);
+			}
+			auto left = [&](auto pr) {
+				constexpr int PR_ = decltype(pr)::value;
+				v4i fv2[2];
+				digit_fragment_pair<PR_>(xv, fv2);
+#pragma unroll
+				for (int b = 0; b < 8; b++) {
+					acc[0][2 * PR_ + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv2[0], fa[b], acc[0][2 * PR_ + b], 0, 0, 0);
+					acc[0][2 * PR_ + 1 + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv2[1], fa[b], acc[0][2 * PR_ + 1 + b], 0, 0, 0);
 				}
+			};
+			left(std::integral_constant<int, 0>{});
+			left(std::integral_constant<int, 1>{});
+			left(std::integral_constant<int, 2>{});
+			left(std::integral_constant<int, 3>{});
+		} else {
+			v4i fv[8];
+			digit_fragments(xv, fv);
+#pragma unroll
+			for (int a = 0; a < 8; a++) {
+#pragma unroll
+				for (int b = 0; b < 8; b++)
+					acc[0][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv[a], fv[b], acc[0][a + b], 0, 0, 0);
 			}
 		}
 		ntl++;
@@ -739,7 +776,7 @@ hipError_t launch_block_dot_mfma(const KernelCfg &c, const void *V, const void *
 {
 	const long long ntiles = (rows + 63) / 64;
 	long long blocks = (ntiles + DBLOCK / 64 - 1) / (DBLOCK / 64);
-	const long long cap = std::min<long long>(max_blocks, (long long)c.num_cu * (c.n == 16 ? 1 : 2));
+	const long long cap = std::min<long long>(max_blocks, (long long)c.num_cu * 2);	/* two wavefronts per SIMD */
 	blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 	*nblocks = (int)blocks;
 	if (c.n == 16)
