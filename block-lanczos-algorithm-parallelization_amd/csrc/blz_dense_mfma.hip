@@ -117,28 +117,19 @@ k_ortho_mfma_prep(const u64 *__restrict__ small, unsigned char *__restrict__ img
 		const int E = 64 * kc + 16 * (ln >> 4) + j;
 		B[idx] = (signed char)signed_digit(rot61(coefficient<NT>(small, ch, E >> 3, ln & 15), 8 * (E & 7)), dg);
 	}
-	/* accumulator start: 128 * (sum over K' of B_t[.][col]) + 2^24; the entries are dealt to the workgroups, the K' of one
-	 * entry to the threads (one thread per entry took 7 us in one workgroup) */
+	/* accumulator start: 128 * (sum over K' of B_t[.][col]) + 2^24: one wavefront per entry, its K' over the lanes (the
+	 * grid has NE / 4 workgroups; a loop over the entries with workgroup-wide sums took 7 us per launch) */
 	constexpr int NE = G::NCH * G::ND * 16;
-	__shared__ int part[4];
-	const int per = (NE + (int)gridDim.x - 1) / (int)gridDim.x;
-	for (int q = 0; q < per; q++) {
-		const int e = blockIdx.x * per + q;		/* uniform over the workgroup */
-		if (e >= NE)
-			break;
+	for (int e = (blockIdx.x * 256 + t) >> 6; e < NE; e += (int)gridDim.x * 4) {
 		const int col = e & 15, dg = (e >> 4) & 7, ch = e >> 7;
 		const int nk = (ch == 0 ? G::KS1 : G::KS2) * 64;
 		int sum = 0;
-		for (int kp = t; kp < nk; kp += 256)
+		for (int kp = t & 63; kp < nk; kp += 64)
 			sum += signed_digit(rot61(coefficient<NT>(small, ch, kp >> 3, col), 8 * (kp & 7)), dg);
 		for (int off = 32; off; off >>= 1)
 			sum += __shfl_xor(sum, off, 64);
 		if ((t & 63) == 0)
-			part[t >> 6] = sum;
-		__syncthreads();
-		if (t == 0)
-			init[e] = 128 * (part[0] + part[1] + part[2] + part[3]) + (1 << 24);
-		__syncthreads();
+			init[e] = 128 * sum + (1 << 24);
 	}
 }
 
@@ -473,7 +464,7 @@ static void ortho_mfma_go(const KernelCfg &c, void *V, const void *AV, void *P, 
 	const long long cap = (long long)c.num_cu * per_cu;
 	blocks = blocks > cap ? cap : blocks;
 	unsigned char *img = (unsigned char *)c.mfma_img;
-	hipLaunchKernelGGL((k_ortho_mfma_prep<NT>), dim3(2 * NT), dim3(256), 0, s, small, img, ctl);
+	hipLaunchKernelGGL((k_ortho_mfma_prep<NT>), dim3(OG<NT>::NCH * OG<NT>::ND * 16 / 4), dim3(256), 0, s, small, img, ctl);
 	const size_t lds = OG<NT, ST>::lds_bytes(threads);
 	hipLaunchKernelGGL((k_ortho_mfma<NT, ST>), dim3((unsigned)blocks), dim3(threads), lds, s, (u64 *)V, (const u64 *)AV, (u64 *)P,
 			   (long long)rows, small, img, ctl);
