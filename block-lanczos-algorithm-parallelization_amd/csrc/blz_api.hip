@@ -275,6 +275,8 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 		c->cfg.mfma = !(nm && nm[0] == '1');
 		/* measured on MI355X: fixed cost 18 us vs 9 us, slope 52 vs 71 us per million rows at n = 8 (cross at 0.5 M rows);
 		 * at n = 16 the vector kernel is compute-bound at 255 us per million rows (cross near 0.1 M rows) */
+		const char *s8 = getenv("BLZ_MFMA_STAGE8");
+		c->cfg.mfma_stage8 = s8 && s8[0] == '1';
 		const char *mr = getenv("BLZ_MFMA_MIN_ROWS");
 		c->cfg.mfma_min_rows = mr ? atoll(mr) : (n == 16 ? 100000 : 500000);
 		c->cfg.mfma_img = nullptr;

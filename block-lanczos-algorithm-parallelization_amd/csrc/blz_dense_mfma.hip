@@ -478,10 +478,9 @@ hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV
 	/* n = 8 (64-byte rows: a fragment load covers 1 KB of consecutive rows anyway) loads fragments straight from HBM:
 	 * the staged form is no faster there (115.6 / 116.0 against 113.9 / 114.6 us on the GL7d19 shape); BLZ_MFMA_STAGE8=1
 	 * takes it for A/B */
-	static const char *se = getenv("BLZ_MFMA_STAGE8");
 	if (c.n == 16)
 		ortho_mfma_go<16, true>(c, V, AV, P, rows, small, ctl, s);
-	else if (se && se[0] == '1')
+	else if (c.mfma_stage8)
 		ortho_mfma_go<8, true>(c, V, AV, P, rows, small, ctl, s);
 	else
 		ortho_mfma_go<8, false>(c, V, AV, P, rows, small, ctl, s);

@@ -74,6 +74,7 @@ struct KernelCfg {
 	hipStream_t side;	/* stream of the outlier-row launches (nullptr: same stream as the streaming kernel; BLZ_NO_SIDE=1) */
 	hipEvent_t ev_fork, ev_join;
 	int mfma;		/* 1: the dense row kernels use the matrix cores where they can (p = 2^61-1, n = 8 / 16); BLZ_NO_MFMA=1 */
+	int mfma_stage8;		/* 1: the n = 8 block update stages its rows through LDS like the n = 16 one (A/B; BLZ_MFMA_STAGE8=1) */
 	long long mfma_min_rows;	/* block update: below this many rows the vector-ALU kernel is quicker (launch + image set-up); BLZ_MFMA_MIN_ROWS */
 	void *mfma_img;		/* device scratch for the coefficient digits in MFMA fragment order (ortho_mfma_image_bytes()) */
 	int panel;		/* 1: slabs whose operand has hot block rows run k_spmv_panel; BLZ_NO_PANEL=1 turns it off */

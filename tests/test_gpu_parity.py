@@ -451,8 +451,10 @@ def test_block_update_on_the_matrix_cores_against_oracle(monkeypatch, n, rows):
     Mo = as_orc(M)
     want = orc.block_lanczos(Mo, n, p, stop_after=4)
     monkeypatch.setenv("BLZ_MFMA_MIN_ROWS", "0")            # (by default small blocks stay on the vector ALU: launch cost)
-    for flag in ("0", "1"):
-        monkeypatch.setenv("BLZ_NO_MFMA", flag)
+    # flag "8": matrix cores with the LDS-staged row loads at n = 8 as well (the default there loads fragments directly)
+    for flag in ("0", "1", "8") if n == 8 else ("0", "1"):
+        monkeypatch.setenv("BLZ_NO_MFMA", "1" if flag == "1" else "0")
+        monkeypatch.setenv("BLZ_MFMA_STAGE8", "1" if flag == "8" else "0")
         with blz.Context(p, n) as ctx:
             ctx.set_matrix(M, False)
             ctx.init_v()
