@@ -328,3 +328,23 @@ def test_short_side_form_of_a_product_sums_to_the_gathering_form(nranks, right):
                         want[r_] += int(G["val"][k]) * xg[G["col_idx"][k]]
                 assert (total[g * stride_out:g * stride_out + G["rows"]] == want).all(), (t, g)
                 assert not total[g * stride_out + G["rows"]:(g + 1) * stride_out].any()     # padding rows stay empty
+
+
+def test_bench_takes_the_real_file_when_the_directory_has_it(tmp_path, monkeypatch):
+    """`$BLZ_MTX_DIR/<name>.mtx` replaces the seeded synthetic of the same workload (the SuiteSparse files
+    are not on the box; a small file under the workload's name stands in here).  Host code only."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    w = dict(bench.WORKLOADS["relat8"])
+    p = w["prime"]
+    small = blz.Matrix.synth(300, 40, 900, 7, p)
+    small.save(str(tmp_path / w["mtx"]))
+    monkeypatch.setenv("BLZ_MTX_DIR", str(tmp_path))
+    M, data = bench.make_matrix(blz, w, p)
+    assert data.startswith("real: ") and (M.nrows, M.ncols, M.nnz) == (300, 40, 900)
+    assert np.array_equal(M.i, small.i) and np.array_equal(M.j, small.j) and np.array_equal(M.x, small.x)
+    monkeypatch.setenv("BLZ_MTX_DIR", str(tmp_path / "nowhere"))
+    w2 = dict(w, rows=500, cols=60, nnz=2000)
+    M2, data2 = bench.make_matrix(blz, w2, p)
+    assert data2 == "synthetic" and (M2.nrows, M2.ncols, M2.nnz) == (500, 60, 2000)
