@@ -18,9 +18,13 @@ row-local block update, all on the GPU with every operand resident in HBM before
 Real matrices: if $BLZ_MTX_DIR holds GL7d19.mtx / relat9.mtx / relat8.mtx they are loaded instead of the seeded
 synthetic stand-ins of the same shape ("data" says which).
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run, one
-process per GPU.  torch.distributed (gloo) carries only the control plane (RCCL id, barrier, max of the
-times, verdicts); the data path's collectives are RCCL calls made by libblz_hip.so on its own stream.
+Launch: python bench.py [--gpus N --steps K --warmup W].  N > 1 runs one process per GPU: either the caller starts
+them (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...: RANK / WORLD_SIZE in the
+environment), or `python bench.py --gpus N` alone does it itself -- the parent, which never touches the GPU, starts
+that same torch.distributed.run command as a CHILD process on a free port of 127.0.0.1, relays the one JSON line and
+the exit code (--dry-run prints the command instead).  torch.distributed (gloo) carries only the control plane (RCCL
+id, barrier, max of the times, verdicts); the data path's collectives are RCCL calls made by libblz_hip.so on its own
+streams.
 """
 import argparse
 import json
@@ -86,6 +90,90 @@ def make_matrix(blz, w, p):
 
 class Stopped(Exception):
     pass
+
+
+def launcher_command(argv, gpus, port):
+    """the command `bench.py --gpus N` runs as its child when nobody has started the ranks: what the driver would type"""
+    rest = [a for a in argv if a != "--dry-run"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + rest
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """N > 1 asked and no launcher around us: start one process per GPU as a child (this process has made no GPU call
+    and imports neither torch nor the library), pass its stderr through, relay its single JSON line and its exit code."""
+    import subprocess
+    cmd = launcher_command(sys.argv[1:], args.gpus, free_port())
+    if args.dry_run:
+        print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "cmd": cmd}))
+        return 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT, text=True)
+    line = None
+    for ln in child.stdout:                 # rank 0 writes exactly one line that starts with '{'; anything else is noise
+        if ln.startswith("{"):
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    code = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif code == 0:
+        code = 1
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+    return code
+
+
+def ctx_width(ctx, n):
+    """block width in HBM (the next power of two unless BLZ_NO_PAD=1): the n x n operands travel padded"""
+    if os.environ.get("BLZ_NO_PAD") == "1":
+        return n
+    g = 1
+    while g < n:
+        g <<= 1
+    return g
+
+
+def host_cpu():
+    """model name and logical CPU count of this host (the CPU baseline is quoted with both)"""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"model": model, "logical_cpus": os.cpu_count()}
+
+
+def gather_ceiling(row_bytes, table_bytes):
+    """The micro-benchmarked ceiling for random block-row gathers (tools/ubench2.hip), read from the committed run
+    profiles/r02_ubench2_gather_requests_tlb_panel.txt: the best plain-load rate for this row size (32 / 64 / 128 B) at
+    the table size nearest to the operand's.  Returns (rows per second, the line it came from) or (None, None)."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r02_ubench2_gather_requests_tlb_panel.txt")
+    want = min((32, 64, 128), key=lambda b: abs(b - row_bytes))
+    best = None
+    try:
+        for ln in open(path):
+            mt = re.match(r"gather\s+hipMalloc\s+plain\s+(\d+)B rows\s+table\s+([0-9.]+) MB.*?([0-9.]+) G rows/s\s*(\S*)", ln)
+            if not mt or int(mt.group(1)) != want or mt.group(4).startswith("window"):
+                continue
+            dist_ = abs(float(mt.group(2)) * 1e6 - table_bytes)
+            key = (dist_, -float(mt.group(3)))
+            if best is None or key < best[0]:
+                best = (key, float(mt.group(3)) * 1e9, ln.strip())
+    except OSError:
+        return None, None
+    return (best[1], f"{os.path.relpath(path, ROOT)}: {best[2]}") if best else (None, None)
 
 
 def measure(blz, torch, dist, ctx, info, w, steps, warmup, repeats):
@@ -163,7 +251,8 @@ def measure(blz, torch, dist, ctx, info, w, steps, warmup, repeats):
     t_spmv_ms = prof["spmv1"]["ms_total"] / max(steps, 1)
     macs_per_step = 2 * info["nnz"] * n
     loc, kind = ctx.locality()
-    return dict(elapsed=elapsed, times=times, device_ms_per_step=statistics.median(dev) / steps, kernels=kernels,
+    return dict(elapsed=elapsed, times=times, device_ms_per_step=statistics.median(dev) / steps, kernels=kernels, prof=prof,
+                loc_rows=(loc_v, loc_t),
                 t_spmv_ms=t_spmv_ms, alg_bytes=bytes1, achieved=bytes1 / (t_spmv_ms * 1e-3) / 1e9, nnz1=nnz1,
                 macs_per_step=macs_per_step, value=macs_per_step * steps / elapsed, word=word, rows_v=rows_v, rows_t=rows_t,
                 renumbering=dict(lines_per_entry=dict(M=loc[0], Mt=loc[1]), order=("smallest", "file", "mean")[kind]),
@@ -201,8 +290,19 @@ def main():
     ap.add_argument("--ref-iterations", type=int, default=50,
                     help="iterations of the unmodified reference OpenMP binary on a 1/4-scale sample (0 = skip)")
     ap.add_argument("--extras", type=int, default=-1,
-                    help="1/0: also run the other single-GPU configs (relat9, relat8); default: only with the default workload at N=1")
+                    help="1/0: also run the other single-GPU workloads (relat9, relat8, config-5 quarter shape, structured); "
+                         "default: only with the default workload at N=1")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print what would be started (for N > 1 without a launcher: the torch.distributed.run command) and exit")
     args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args))
+    if args.dry_run:
+        print(json.dumps({"dry_run": True, "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+                          "cmd": [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--dry-run"]}))
+        return
 
     # stdout carries exactly ONE line (the JSON): RCCL and gloo print banners to fd 1 from native code, so fd 1 is
     # pointed at stderr for the duration of the run and the result is written to the saved descriptor
@@ -213,9 +313,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    if world != args.gpus:          # a launcher's WORLD_SIZE wins over the flag
         args.gpus = world
 
     if world > 1 and "OMP_NUM_THREADS" not in os.environ:
@@ -327,8 +425,10 @@ def main():
         r = measure(blz, torch, dist, ctx, info, w, args.steps, args.warmup, max(1, args.repeats))
     except Stopped as exc:
         leave(1, str(exc))
-    traffic, traffic_src = spmv_traffic(args.workload, world)
+    traffic, traffic_src = spmv_traffic(args.workload, world)      # None for any (workload, N) without a committed PMC run
     t_spmv_ms = r["t_spmv_ms"]
+    # the first SpMV gathers block rows of v (n words each) out of the whole block
+    ceiling, ceiling_src = gather_ceiling(n * r["word"], r["rows_v"] * n * r["word"])
 
     out = {
         "metric": "nnz*n mod-p MAC/s",
@@ -372,8 +472,10 @@ def main():
             # the micro-benchmarked ceiling for random block-row gathers on MI355X is ~55 G rows/s whatever the row size
             # up to 128 B, the allocation kind or the load policy (profiles/r02_ubench2_*) = 7.0 TB/s of line traffic
             "gathers_per_s": r["nnz1"] / (t_spmv_ms * 1e-3) if t_spmv_ms else None,
-            "gather_ceiling_per_s": 55e9,
+            "gather_ceiling_per_s": ceiling,
+            "gather_ceiling_source": ceiling_src,
         },
+        "host": host_cpu(),
         "device_ms_per_step": r["device_ms_per_step"],
         "kernels": r["kernels"],
         "setup_s": {"generate_or_load": t_gen, "csr_upload_init": t_setup,
@@ -382,6 +484,53 @@ def main():
         "lds_panel": r["lds_panel"],
     }
     macs_per_step, rows_v, rows_t = r["macs_per_step"], r["rows_v"], r["rows_t"]
+
+    # ---- several ranks (or the exchange forced on one): what RCCL saw, how the exchange was cut, what each collective
+    # cost and how much of it the products hid -- enough to fit the piece model (t0 per call, gather rate) from ONE run
+    if dist is not None:
+        seen, me = ctx.comm_info()
+        prof, word = r["prof"], r["word"]
+        # padded slab rows of each side = the largest rank's share (ncclAllGather moves equal counts)
+        pad = torch.tensor(list(r["loc_rows"]), dtype=torch.int64)
+        dist.all_reduce(pad, op=dist.ReduceOp.MAX)
+        stride_v, stride_t = int(pad[0]), int(pad[1])
+        seen_t = torch.tensor([seen], dtype=torch.int64)
+        dist.all_reduce(seen_t, op=dist.ReduceOp.MIN)
+        nn2 = 2 * ctx_width(ctx, n) ** 2 * 8
+        per_call = {"allgather_v": stride_v * n * word * world, "allgather_tmp": stride_t * n * word * world,
+                    "allreduce": nn2, "reduce_scatter": min(stride_v, stride_t) * n * 8 * world}       # (the short side's block)
+        factor = {"allgather_v": (world - 1) / world, "allgather_tmp": (world - 1) / world,
+                  "allreduce": 2 * (world - 1) / world, "reduce_scatter": (world - 1) / world}
+        coll, exch_ms = {}, 0.0
+        for name in ("allgather_v", "allgather_tmp", "allreduce", "reduce_scatter"):
+            v_ = prof.get(name)
+            if not v_ or not v_["launches"]:
+                continue
+            calls = v_["launches"] / args.steps
+            ms_step = v_["ms_total"] / args.steps
+            exch_ms += ms_step
+            ent = {"calls_per_step": calls, "ms_per_step": ms_step, "ms_per_call": v_["ms_total"] / v_["launches"]}
+            total = per_call[name]
+            if name.startswith("allgather"):
+                total = total / max(calls, 1)         # K pieces per step: each call moves 1/K of the block
+            if total:
+                ent["bytes_per_call_all_ranks"] = total
+                ent["alg_GBps"] = total / (ent["ms_per_call"] * 1e-3) / 1e9
+                ent["bus_GBps"] = ent["alg_GBps"] * factor[name]
+            coll[name] = ent
+        comp_ms = sum(prof[k_]["ms_total"] for k_ in ("spmv1", "spmv2", "block_dot", "semi_inverse", "orthogonalize")) / args.steps
+        step_ms = r["device_ms_per_step"]
+        exposed = max(0.0, step_ms - comp_ms)
+        out["multi_gpu"] = {
+            "rccl_ranks_seen": int(seen_t[0]), "rccl_rank_of_rank0": me,
+            "pieces": {"spmv1": ctx.exchange_pieces(not right), "spmv2": ctx.exchange_pieces(right)},
+            "short_side": {"spmv1": ctx.short_side(not right), "spmv2": ctx.short_side(right)},
+            "collectives": coll,
+            "note": "HIP-event spans on rank 0: collectives on the exchange stream (all-gathers) or the compute stream "
+                    "(all-reduce, reduce-scatter); compute = the five kernel classes on the compute stream",
+            "exchange_ms_per_step": exch_ms, "compute_ms_per_step": comp_ms, "device_ms_per_step": step_ms,
+            "exposed_exchange_ms_per_step": exposed, "hidden_exchange_ms_per_step": max(0.0, exch_ms - exposed),
+        }
 
     # ---- CPU baseline on this box's host cores: bounded sample of the same workload ------------
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -415,7 +564,8 @@ def main():
             "kind": "port",
             "sample": f"{best['iterations']} full iteration(s) of the same workload with the oracle's by-rows OpenMP kernels "
                       f"(CSR built once, 128-bit sums; restating openMP/lanczos_modp.c with the output rows as the parallel "
-                      f"loop), {best['s_per_iteration'] * best['iterations']:.1f} s on {ncpu} host CPUs; the better of "
+                      f"loop), {best['s_per_iteration'] * best['iterations']:.1f} s on {ncpu} host CPUs "
+                      f"({host_cpu()['model']}); the better of "
                       f"{[q['cores'] for q in runs]} threads",
             "s_per_iteration": best["s_per_iteration"],
             "runs": runs,
@@ -509,22 +659,34 @@ def main():
     want_extras = (args.extras == 1) or (args.extras < 0 and args.workload == "gl7d19" and world == 1 and dist is None)
     if want_extras and verdict:
         out["extra"] = {"workloads": {}}
-        for name in ("relat9", "relat8"):
+        # relat9 / relat8 shapes = configs 3 / 2; synth5q = ONE GPU's quarter-scale share of config 5 (n = 16, 128-byte block
+        # rows out of a 1.6 GB operand: the shape 91 % of whose iteration is the SpMV); nfs = the structured extra workload
+        for name in ("relat9", "relat8", "synth5q", "nfs"):
             we = WORKLOADS[name]
             try:
+                t0 = time.time()
                 Me, data_e = make_matrix(blz, we, we["prime"])
                 ce = blz.Context(we["prime"], we["n"], device=local_rank)
                 ce.set_matrix(Me, we["right"])
                 ce.init_v()
-                re_ = measure(blz, torch, None, ce, dict(nnz=Me.nnz, pattern=bool((Me.x == 1).all())), we, args.steps, args.warmup, 3)
+                t_set = time.time() - t0
+                steps_e = min(args.steps, 10) if Me.nnz > 200000000 else args.steps      # 25 ms per step there
+                re_ = measure(blz, torch, None, ce, dict(nnz=Me.nnz, pattern=bool((Me.x == 1).all())), we, steps_e, args.warmup, 3)
                 ce.close()
+                tr_e, tr_src = spmv_traffic(name, 1)
+                ceil_e, ceil_src = gather_ceiling(we["n"] * re_["word"], re_["rows_v"] * we["n"] * re_["word"])
                 out["extra"]["workloads"][name] = {
                     "workload": f"{we['desc']}: {Me.nrows}x{Me.ncols}, {Me.nnz} nnz, --prime {prime_name(we['prime'])} --n {we['n']} "
                                 f"{'--right' if we['right'] else '--left'}",
-                    "data": data_e, "value": re_["value"], "unit": "MAC/s", "ms_per_step": re_["elapsed"] / args.steps * 1e3,
+                    "data": data_e, "value": re_["value"], "unit": "MAC/s", "steps": steps_e, "ms_per_step": re_["elapsed"] / steps_e * 1e3,
                     "roofline_frac": re_["achieved"] / HBM_PEAK_GBPS, "spmv1_GBps": re_["achieved"],
+                    "spmv1_alg_bytes": re_["alg_bytes"], "spmv1_traffic": tr_e, "spmv1_traffic_source": tr_src,
                     "spmv1_ms": re_["t_spmv_ms"], "gathers_per_s": re_["nnz1"] / (re_["t_spmv_ms"] * 1e-3),
+                    "spmv2_gathers_per_s": (Me.nnz / (re_["kernels"]["spmv2"]["ms_mean"] * 1e-3)
+                                            if re_["kernels"]["spmv2"]["ms_mean"] else None),
+                    "gather_ceiling_per_s": ceil_e, "gather_ceiling_source": ceil_src,
                     "kernels_ms": {k_: v_["ms_mean"] for k_, v_ in re_["kernels"].items() if v_["ms_mean"]},
+                    "setup_s": t_set,
                 }
                 del Me
             except Exception as exc:    # an extra never costs the headline line

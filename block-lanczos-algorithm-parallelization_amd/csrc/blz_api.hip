@@ -41,6 +41,8 @@ struct Rccl {
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
 	ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+	ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 	ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -72,6 +74,8 @@ int rccl_load()
 	SYM(AllGather, "ncclAllGather")
 	SYM(AllReduce, "ncclAllReduce")
 	SYM(ReduceScatter, "ncclReduceScatter")
+	SYM(CommCount, "ncclCommCount")
+	SYM(CommUserRank, "ncclCommUserRank")
 	SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
 	g_rccl.handle = h;
@@ -111,7 +115,7 @@ struct blz_ctx {
 	std::vector<DevCsr> csr[2];			/* column pieces of this rank's rows of M / M^T */
 	int row_side[2] = { 0, 1 };			/* side of the rows of csr[t] */
 	void *slab[4] = { nullptr, nullptr, nullptr, nullptr };
-	size_t slab_bytes = 0;
+	size_t slab_bytes[4] = { 0, 0, 0, 0 };	/* several ranks: each block sized by its own side (V, AV, P: rows of v; TMP: the other side) */
 	void *gath[2] = { nullptr, nullptr };		/* gathered operands (nranks > 1) */
 	int gath_holds[2] = { -1, -1 };			/* which block each one currently holds */
 	int ag_chunks = 0;				/* pieces per all-gather: BLZ_AG_CHUNKS, 0 = choose from the slab size */
@@ -120,6 +124,8 @@ struct blz_ctx {
 	std::vector<hipEvent_t> ev_piece;		/* piece k of the exchange has landed */
 	u64 *small = nullptr, *partial = nullptr;
 	u64 *dot_send = nullptr;	/* this rank's vtAv | vtAAv before the all-reduce (several ranks): 2 n^2 words */
+	u64 *dot_recv = nullptr;	/* where the all-reduce lands: sums of the ranks' residues; the semi-inverse kernel reads them
+					 * and writes residues to `small` -- unless the stop flag is up (round 3) */
 	int max_dot_blocks = 0;
 	DevCtl *ctl = nullptr;
 	DevCtl host_ctl{};
@@ -149,6 +155,9 @@ struct blz_ctx {
 	DevCsr csr_short[2];
 	void *part = nullptr;		/* partial product, nranks x stride[output side] rows (u64 words) */
 	size_t part_bytes = 0;
+	void *rs_recv = nullptr;	/* where the reduce-scatter of `part` lands (stride rows); k_reduce_modp copies it into the slab
+					 * as residues unless the stop flag is up (round 3) */
+	size_t rs_bytes = 0;
 	double hot_share[2] = { 0.0, 0.0 };	/* share of the entries held by the rows / columns numbered first */
 	double locality[2] = { 1.0, 1.0 };	/* lines per gathered entry in windows of rows, product M*x / M^T*x */
 	int order_kind = 0;			/* which order blz_reorder_auto chose */
@@ -259,6 +268,8 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	{
 		const char *ns = getenv("BLZ_NO_STAGE");
 		c->cfg.staged = !(ns && ns[0] == '1');
+		const char *su = getenv("BLZ_STAGE_U");		/* gathers in flight per lane of the staged SpMV: 4 / 8 (A/B); 0 = by plan */
+		c->cfg.stage_u = su ? atoi(su) : 0;
 	}
 	{
 		const char *nsd = getenv("BLZ_NO_SIDE");
@@ -306,6 +317,8 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 	HIPCHK(hipMemset(c->small, 0, small_words(np_) * sizeof(u64)));
 	HIPCHK(hipMalloc(&c->dot_send, (size_t)2 * np_ * np_ * sizeof(u64)));
 	HIPCHK(hipMemset(c->dot_send, 0, (size_t)2 * np_ * np_ * sizeof(u64)));
+	HIPCHK(hipMalloc(&c->dot_recv, (size_t)2 * np_ * np_ * sizeof(u64)));
+	HIPCHK(hipMemset(c->dot_recv, 0, (size_t)2 * np_ * np_ * sizeof(u64)));
 	/* partial rows of the inner products: the fused path (n <= 8) needs room for the streaming kernel plus the
 	 * outlier launches; the stand-alone kernel keeps the grid it was tuned with */
 	c->max_dot_blocks = c->cfg.num_cu * (np_ <= 8 ? 16 : 8);
@@ -363,6 +376,8 @@ extern "C" void blz_destroy(blz_ctx *c)
 		if (d) hipFree(d);
 	if (c->small) hipFree(c->small);
 	if (c->dot_send) hipFree(c->dot_send);
+	if (c->dot_recv) hipFree(c->dot_recv);
+	if (c->rs_recv) hipFree(c->rs_recv);
 	if (c->cfg.mfma_img) hipFree(c->cfg.mfma_img);
 	if (c->cfg.side) {
 		hipStreamSynchronize(c->cfg.side);
@@ -613,7 +628,7 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 	int rc = BLZ_OK;
 	/* Short-side form of a product whose operand side is at least 8 times longer than its output side (64-bit words:
 	 * the partial sums travel as u64).  BLZ_SHORT_SIDE=0 / 1 forces it off / on (tests, A/B). */
-	size_t part_need = 0;
+	size_t part_need = 0, rs_need = 0;
 	for (int t = 0; t < 2; t++) {
 		free_csr(c->csr_short[t]);
 		const int rs_t = c->row_side[t], cs_t = 1 - rs_t;
@@ -621,8 +636,10 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 		if (const char *e = getenv("BLZ_SHORT_SIDE"))
 			on = e[0] == '1' && c->cfg.word == 8 && (nranks > 1 || c->force_comm);
 		c->short_side[t] = on;
-		if (on)
+		if (on) {
 			part_need = std::max(part_need, (size_t)nranks * (size_t)std::max<int64_t>(c->stride[rs_t], 1) * c->cfg.n * 8);
+			rs_need = std::max(rs_need, (size_t)std::max<int64_t>(c->stride[rs_t], 1) * c->cfg.n * 8);
+		}
 	}
 	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
 		if (c->short_side[t]) {
@@ -672,16 +689,27 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 		HIPCHK(hipMalloc(&c->part, part_need));
 		c->part_bytes = part_need;
 	}
-	const int64_t slab_rows = std::max<int64_t>(std::max(c->stride[0], c->stride[1]), 1);
-	const size_t bytes = (size_t)slab_rows * c->cfg.n * c->cfg.word;
+	if (rs_need > c->rs_bytes) {
+		if (c->rs_recv)
+			hipFree(c->rs_recv);
+		c->rs_recv = nullptr;
+		HIPCHK(hipMalloc(&c->rs_recv, rs_need));
+		c->rs_bytes = rs_need;
+	}
+	/* One rank: every block can hold either side (the reference sizes all four for the larger one, :597-605, and
+	 * blz_spmv takes any pair of blocks).  Several ranks: a block lives on ONE side (side_of), and a rank's slab of the
+	 * long side of a tall matrix is many times its slab of the short one (relat9 shape at N = 8: 1.5 M rows against
+	 * 69 k) -- each block is sized by its own side (round 2 gave all four the larger: 23 x what V, AV and P need there). */
 	for (int b = 0; b < 4; b++) {
+		const int64_t rows = nranks == 1 ? std::max(c->stride[0], c->stride[1]) : c->stride[side_of(b)];
+		const size_t bytes = (size_t)std::max<int64_t>(rows, 1) * c->cfg.n * c->cfg.word;
 		if (c->slab[b])
 			hipFree(c->slab[b]);
 		c->slab[b] = nullptr;
 		HIPCHK(hipMalloc(&c->slab[b], bytes));
 		HIPCHK(hipMemset(c->slab[b], 0, bytes));		/* sequential/lanczos_modp.c:617-622 */
+		c->slab_bytes[b] = bytes;
 	}
-	c->slab_bytes = bytes;
 	for (int sd = 0; sd < 2; sd++) {
 		if (c->gath[sd])
 			hipFree(c->gath[sd]);
@@ -1013,7 +1041,7 @@ extern "C" int blz_init_v(blz_ctx *c)
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipStreamSynchronize(c->xstream));
 	for (int b = 0; b < 4; b++)
-		HIPCHK(hipMemset(c->slab[b], 0, c->slab_bytes));
+		HIPCHK(hipMemset(c->slab[b], 0, c->slab_bytes[b]));
 	c->gath_holds[0] = c->gath_holds[1] = -1;
 	HIPCHK(hipMemset(c->ctl, 0, sizeof(DevCtl)));
 	c->host_ctl = DevCtl{};
@@ -1055,15 +1083,19 @@ static int allreduce_dots(blz_ctx *c)
 	Span sp(c, PK_AR);
 	/* residues < p and nranks * p <= 2^64 (checked in blz_set_matrix): the u64 sum cannot wrap; the
 	 * semi_inverse kernel reduces it mod p.  (mpi/lanczos_modp.c:1209-1247 does this by hand.)
-	 * Out of place, from the rank's own partial sums (dot_out) into `small`: once the stop flag is up k_dot_finalize
-	 * leaves dot_send alone, so the iterations a batch enqueues past the stop reduce the same words again and `small`
-	 * keeps its value (in place, every such iteration multiplied it by the number of ranks). */
-	NCCLCHK(g_rccl.AllReduce(c->dot_send, c->small, (size_t)2 * c->cfg.n * c->cfg.n, ncclUint64, ncclSum, c->comm,
+	 * From the rank's own partial sums (dot_send) into a landing place of its own (dot_recv), never into `small`: the
+	 * collective is enqueued by the host whatever the stop flag says, and the iterations a batch enqueues past the stop
+	 * would leave raw sums (up to nranks * (p - 1)) in `small` -- the semi-inverse kernel, the one that turns them
+	 * into residues, is a no-op by then.  It reads dot_recv and writes `small` only while the flag is down. */
+	NCCLCHK(g_rccl.AllReduce(c->dot_send, c->dot_recv, (size_t)2 * c->cfg.n * c->cfg.n, ncclUint64, ncclSum, c->comm,
 				 c->stream));
 	return BLZ_OK;
 }
 
 static inline u64 *dot_out(blz_ctx *c) { return exchanging(c) ? c->dot_send : c->small; }
+
+/* where the semi-inverse finds vtAv | vtAAv */
+static inline const u64 *dot_sums(blz_ctx *c) { return exchanging(c) ? c->dot_recv : c->small; }
 
 /*
  * One product of the iteration: slab[dst] = (transpose ? M^T : M)[this rank's rows] * block `src`, with the
@@ -1092,10 +1124,12 @@ static int enqueue_product(blz_ctx *c, int transpose, int src, int dst, bool wit
 				return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
 			{
 				Span sp(c, PK_RS);
-				NCCLCHK(g_rccl.ReduceScatter(c->part, c->slab[dst], (size_t)c->stride[rs_t] * c->cfg.n, ncclUint64, ncclSum,
+				NCCLCHK(g_rccl.ReduceScatter(c->part, c->rs_recv, (size_t)c->stride[rs_t] * c->cfg.n, ncclUint64, ncclSum,
 							     c->comm, c->stream));
 			}
-			HIPCHK(launch_reduce_modp(c->cfg, c->slab[dst], c->count[rs_t] * c->cfg.n, c->ctl, c->stream));
+			/* out of place and stop-aware: past the stop `part` is stale (possibly the OTHER product's), the collective
+			 * runs all the same, and slab[dst] must keep the last real product (blz_final_check reads TMP) */
+			HIPCHK(launch_reduce_modp(c->cfg, c->slab[dst], c->rs_recv, c->count[rs_t] * c->cfg.n, c->ctl, c->stream));
 		}
 		return BLZ_OK;
 	}
@@ -1154,11 +1188,11 @@ static int enqueue_dot(blz_ctx *c)
 	return allreduce_dots(c);
 }
 
-static int enqueue_ortho(blz_ctx *c)
+static int enqueue_ortho(blz_ctx *c, bool img_ready = false)
 {
 	Span sp(c, PK_ORTHO);
 	HIPCHK(launch_orthogonalize(c->cfg, slab_ptr(c, BLZ_V), slab_ptr(c, BLZ_AV), slab_ptr(c, BLZ_P), c->count[0],
-				    c->small, c->ctl, c->stream));
+				    c->small, c->ctl, c->stream, img_ready));
 	return BLZ_OK;
 }
 
@@ -1175,6 +1209,12 @@ extern "C" int blz_spmv(blz_ctx *c, int transpose, int src_block, int dst_block)
 	NEED_MATRIX(c);
 	if (src_block < 0 || src_block > 3 || dst_block < 0 || dst_block > 3 || src_block == dst_block)
 		return blz_fail(BLZ_EINVAL, "blz_spmv: bad block selectors");
+	{	/* several ranks: a block lives on one side and its slab is sized for that side only */
+		const int t = transpose ? 1 : 0;
+		if (c->nranks > 1 && (side_of(dst_block) != c->row_side[t] || side_of(src_block) != 1 - c->row_side[t]))
+			return blz_fail(BLZ_EINVAL, "blz_spmv: on several ranks product %d reads a block of side %d and writes one of side %d",
+					t, 1 - c->row_side[t], c->row_side[t]);
+	}
 	int rc = enqueue_spmv(c, transpose ? 1 : 0, src_block, dst_block);
 	if (rc != BLZ_OK)
 		return rc;
@@ -1191,9 +1231,11 @@ extern "C" int blz_block_dot(blz_ctx *c, uint64_t *vtAv, uint64_t *vtAAv)
 	HIPCHK(hipStreamSynchronize(c->stream));
 	const int np = c->cfg.n, un = c->un, nn = np * np;
 	std::vector<u64> h((size_t)2 * nn);
+	if (exchanging(c)) {	/* the sums over the ranks -> residues in `small`, where a following blz_semi_inverse looks */
+		HIPCHK(launch_reduce_modp(c->cfg, c->small, c->dot_recv, 2 * nn, c->ctl, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
 	HIPCHK(hipMemcpy(h.data(), c->small, (size_t)2 * nn * sizeof(u64), hipMemcpyDeviceToHost));
-	for (int e = 0; e < 2 * nn; e++)
-		h[(size_t)e] %= c->prime;	/* multi-rank sums are reduced by the next kernel; mirror it here */
 	for (int i = 0; i < un; i++) {
 		if (vtAv)
 			memcpy(vtAv + (size_t)i * un, h.data() + (size_t)i * np, (size_t)un * sizeof(u64));
@@ -1208,7 +1250,7 @@ extern "C" int blz_semi_inverse(blz_ctx *c, int *npiv, uint64_t *winv, uint64_t 
 	if (!c)
 		return blz_fail(BLZ_EINVAL, "blz_semi_inverse: NULL context");
 	HIPCHK(hipSetDevice(c->device));
-	HIPCHK(launch_semi_inverse(c->cfg, c->small, c->ctl, 0, c->stream));
+	HIPCHK(launch_semi_inverse(c->cfg, c->small, c->small, c->ctl, 0, 0, c->stream));
 	int rc = fetch_ctl(c);
 	if (rc != BLZ_OK)
 		return rc;
@@ -1248,11 +1290,14 @@ static int enqueue_iteration(blz_ctx *c)
 		if ((rc = enqueue_product(c, c->right, BLZ_TMP, BLZ_AV, false, nullptr)) != BLZ_OK) return rc;	/* :636 */
 		if ((rc = enqueue_dot(c)) != BLZ_OK) return rc;				/* :640 */
 	}
+	/* the semi-inverse kernel also writes the coefficient image when the block update runs on the matrix cores
+	 * (round 2: a launch of its own between the two) */
+	const bool img = ortho_uses_mfma(c->cfg, c->count[0]);
 	{
 		Span sp(c, PK_SEMI);
-		HIPCHK(launch_semi_inverse(c->cfg, c->small, c->ctl, 1, c->stream));	/* :644 */
+		HIPCHK(launch_semi_inverse(c->cfg, dot_sums(c), c->small, c->ctl, 1, img, c->stream));	/* :644 */
 	}
-	return enqueue_ortho(c);							/* :652-656 */
+	return enqueue_ortho(c, img);							/* :652-656 */
 }
 
 extern "C" int blz_iterate(blz_ctx *c, int max_iters, int *done, int *stopped, float *ms)
@@ -1541,4 +1586,28 @@ extern "C" int blz_comm_init(blz_ctx *c, const void *id, size_t id_bytes, int ra
 	const char *f = getenv("BLZ_FORCE_COMM");
 	c->force_comm = f && f[0] == '1';
 	return BLZ_OK;
+}
+
+extern "C" int blz_comm_info(const blz_ctx *c, int *nranks_seen, int *rank_seen)
+{
+	if (!c)
+		return blz_fail(BLZ_EINVAL, "blz_comm_info: NULL context");
+	int cnt = -1, rk = -1;
+	if (c->comm) {
+		NCCLCHK(g_rccl.CommCount(c->comm, &cnt));
+		NCCLCHK(g_rccl.CommUserRank(c->comm, &rk));
+	}
+	if (nranks_seen)
+		*nranks_seen = cnt;
+	if (rank_seen)
+		*rank_seen = rk;
+	return BLZ_OK;
+}
+
+extern "C" int blz_exchange_pieces(const blz_ctx *c, int transpose)
+{
+	if (!c || !c->have_matrix)
+		return -1;
+	const int t = transpose ? 1 : 0;
+	return c->short_side[t] ? 0 : (int)c->csr[t].size();
 }

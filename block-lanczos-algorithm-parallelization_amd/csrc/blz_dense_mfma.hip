@@ -28,6 +28,7 @@
  * n = 8:  one chain, [v | p] x [[c | winv] ; [vtAvd | 0]] (K' = 128, 2 per t): columns 0..7 of the tile are v', 8..15 p'.
  */
 #include "blz_kernels.h"
+#include "ortho_img.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -35,70 +36,8 @@
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-
-template <int NT, bool ST = true>
-struct OG {
-	static constexpr int KS1 = NT == 16 ? 4 : 2, KS2 = NT == 16 ? 2 : 0, KS = KS1 + KS2, NCH = NT == 16 ? 2 : 1;
-	static constexpr int ND = 8;		/* digit positions of a multiplier */
-	static constexpr size_t B_BYTES = (size_t)KS * ND * 64 * 16, INIT_BYTES = (size_t)NCH * ND * 16 * 4;
-	static constexpr size_t IMG_BYTES = B_BYTES + INIT_BYTES;
-	/* n = 16 stages the rows through LDS; per wavefront 16 rows of v and 16 of p, row stride = row bytes + 16 (bank spread) */
-	static constexpr bool STAGED = ST;
-	static constexpr bool PREFETCH = ST;		/* load the next tile during the arithmetic: the direct form lost by it (150 vs 124 us) */
-	static constexpr int RSTR = NT * 8 + 16;
-	static constexpr size_t STAGE_BYTES = STAGED ? (size_t)3 * 16 * RSTR : 0;	/* v, p, Av */
-	static constexpr size_t lds_bytes(int threads) { return IMG_BYTES + (size_t)(threads / 64) * STAGE_BYTES; }
-	/* threads per workgroup (BLZ_MFMA_BLOCK takes fewer).  n = 16: ONE workgroup of 16 wavefronts per CU next to the 49 KB image
-	 * and their 108 KB of staging areas -- 1.77 ms with 2 x 4 wavefronts, 1.56 with 12, 1.49 with 16 on the config-5 quarter
-	 * shape, which is what a bare streaming kernel with this traffic reaches.  n = 8: 256 (five workgroups per CU). */
-	static constexpr int THREADS = !ST ? 256 : (NT == 16 ? 1024 : 768);
-};
-
 /* weight of digit sum s in the folded result: 2^(8 s mod 61), applied as a 32-bit multiplier into L (shift < 32) or H */
 __host__ __device__ constexpr int fold_shift(int s) { return (8 * s) % 61; }
-
-/* digit t (signed, base 256) of x < 2^62: with C = 0x8080...80, x = sum_t (byte_t(x + C) - 128) 256^t and every
- * byte_t - 128 lies in [-128, 127]; x + C does not wrap. */
-MODP_DEV int signed_digit(u64 x, int t)
-{
-	return (int)(((x + 0x8080808080808080ull) >> (8 * t)) & 0xFF) - 128;
-}
-
-/* x * 2^sh mod 2^61 - 1 for x < 2^61, sh < 61: a rotation of the 61-bit word */
-MODP_DEV u64 rot61(u64 x, int sh)
-{
-	const u64 P = (1ull << 61) - 1;
-	const u64 r = ((x << sh) & P) | (x >> (61 - sh));
-	return sh == 0 ? x : (r == P ? 0 : r);
-}
-
-/* coefficient of K' word kk and tile column col for chain ch: which matrix, which entry (or none) */
-template <int NT>
-__device__ static int coef_index(int ch, int kk, int col)
-{
-	/* returns an index into the digit table [3][NT*NT]: 0 = c, 1 = vtAvd, 2 = winv; -1 = zero */
-	if (NT == 16) {
-		if (ch == 0)
-			return kk < 16 ? 0 * 256 + kk * 16 + col : 1 * 256 + (kk - 16) * 16 + col;
-		return 2 * 256 + kk * 16 + col;
-	}
-	if (col < 8)
-		return kk < 8 ? 0 * 64 + kk * 8 + col : 1 * 64 + (kk - 8) * 8 + col;
-	return kk < 8 ? 2 * 64 + kk * 8 + (col - 8) : -1;
-}
-
-/* coefficient of word kk and tile column col in chain ch (0 where the chain has none); the multiplier of K' = (kk, byte a)
- * is rot61(coefficient, 8 a) = coefficient * 2^(8a) mod p */
-template <int NT>
-__device__ static u64 coefficient(const u64 *small, int ch, int kk, int col)
-{
-	constexpr int NN = NT * NT;
-	const int ci = coef_index<NT>(ch, kk, col);
-	if (ci < 0)
-		return 0;
-	const int mat = ci / NN, at = ci % NN;
-	return small[(mat == 0 ? 4 : (mat == 1 ? 5 : 2)) * NN + at];
-}
 
 template <int NT>
 __global__ void __launch_bounds__(256)
@@ -454,7 +393,7 @@ static void ortho_mfma_shape(int *threads, int *per_cu)
 
 template <int NT, bool ST>
 static void ortho_mfma_go(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows, const u64 *small, const DevCtl *ctl,
-			  hipStream_t s)
+			  hipStream_t s, bool img_ready)
 {
 	int threads = 0, per_cu = 0;
 	ortho_mfma_shape<NT, ST>(&threads, &per_cu);
@@ -464,14 +403,15 @@ static void ortho_mfma_go(const KernelCfg &c, void *V, const void *AV, void *P, 
 	const long long cap = (long long)c.num_cu * per_cu;
 	blocks = blocks > cap ? cap : blocks;
 	unsigned char *img = (unsigned char *)c.mfma_img;
-	hipLaunchKernelGGL((k_ortho_mfma_prep<NT>), dim3(OG<NT>::NCH * OG<NT>::ND * 16 / 4), dim3(256), 0, s, small, img, ctl);
+	if (!img_ready)		/* inside the iteration the semi-inverse kernel has built the image already */
+		hipLaunchKernelGGL((k_ortho_mfma_prep<NT>), dim3(OG<NT>::NCH * OG<NT>::ND * 16 / 4), dim3(256), 0, s, small, img, ctl);
 	const size_t lds = OG<NT, ST>::lds_bytes(threads);
 	hipLaunchKernelGGL((k_ortho_mfma<NT, ST>), dim3((unsigned)blocks), dim3(threads), lds, s, (u64 *)V, (const u64 *)AV, (u64 *)P,
 			   (long long)rows, small, img, ctl);
 }
 
 hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows, const u64 *small,
-				     const DevCtl *ctl, hipStream_t s)
+				     const DevCtl *ctl, hipStream_t s, bool img_ready)
 {
 	if (rows <= 0)
 		return hipSuccess;
@@ -479,11 +419,11 @@ hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV
 	 * the staged form is no faster there (115.6 / 116.0 against 113.9 / 114.6 us on the GL7d19 shape); BLZ_MFMA_STAGE8=1
 	 * takes it for A/B */
 	if (c.n == 16)
-		ortho_mfma_go<16, true>(c, V, AV, P, rows, small, ctl, s);
+		ortho_mfma_go<16, true>(c, V, AV, P, rows, small, ctl, s, img_ready);
 	else if (c.mfma_stage8)
-		ortho_mfma_go<8, true>(c, V, AV, P, rows, small, ctl, s);
+		ortho_mfma_go<8, true>(c, V, AV, P, rows, small, ctl, s, img_ready);
 	else
-		ortho_mfma_go<8, false>(c, V, AV, P, rows, small, ctl, s);
+		ortho_mfma_go<8, false>(c, V, AV, P, rows, small, ctl, s, img_ready);
 	return hipGetLastError();
 }
 

@@ -34,6 +34,8 @@ struct blz_prepared {
 	int64_t *bounds[2];			/* per SIDE (0: rows of v, 1: rows of tmp): nranks + 1 row bounds */
 	int64_t stride[2];			/* per side: rows of a padded slab */
 	blz_csr full[2];			/* CSR of M and of M^T in the solver's numbering, global column indices */
+	int only_rank;				/* -1: full[] hold every row; >= 0 (blz_prepare_rank): full[t] holds only that rank's rows, */
+	int64_t full_first[2];			/* ... row q of full[t] being global row full_first[t] + q */
 	void *map;
 	size_t map_len;
 };

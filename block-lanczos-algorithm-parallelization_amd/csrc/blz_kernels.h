@@ -79,6 +79,7 @@ struct KernelCfg {
 	void *mfma_img;		/* device scratch for the coefficient digits in MFMA fragment order (ortho_mfma_image_bytes()) */
 	int panel;		/* 1: slabs whose operand has hot block rows run k_spmv_panel; BLZ_NO_PANEL=1 turns it off */
 	int staged;		/* 1: slabs with a plan run k_spmv_staged; BLZ_NO_STAGE=1 keeps the round-1 kernels (A/B) */
+	int stage_u;		/* 0: gathers in flight per lane of the staged SpMV chosen by the slab's plan; 4 / 8: forced (BLZ_STAGE_U, read once) */
 };
 
 /* fills the st_* fields of D from the host copy of its row pointers (D.rows, D.nnz, D.val, D.palette, D.kept_mean,
@@ -114,11 +115,18 @@ hipError_t launch_dot_finalize(const KernelCfg &c, const u64 *partial, int nbloc
 /* small: [vtAv | vtAAv | winv | d | c | vtAvd], n*n words each (d: n words, padded to n*n).
  * Reads vtAv/vtAAv (reduced mod p first: they may be sums over ranks), writes the rest and
  * updates ctl.  sequential/lanczos_modp.c:342-438 and :460-475. */
-hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int in_loop, hipStream_t s);
+hipError_t launch_semi_inverse(const KernelCfg &c, const u64 *sums, u64 *small, DevCtl *ctl, int in_loop, int build_img,
+			       hipStream_t s);
+/* `sums` = the 2 n^2 words vtAv | vtAAv the kernel starts from: `small` itself on one rank, the landing place of the
+ * all-reduce on several (sums of the ranks' residues; the kernel writes their residues to `small` unless the stop flag
+ * is up, so `small` never holds anything but residues).  build_img != 0: the kernel also writes the coefficient image
+ * of the matrix-core block update (c.mfma_img; ortho_mfma_supported(c) must hold): one launch instead of two. */
 
 /* Row-local update in place: V <- v', P <- p'.  sequential/lanczos_modp.c:478-491, :655-656 */
 hipError_t launch_orthogonalize(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows,
-				const u64 *small, const DevCtl *ctl, hipStream_t s);
+				const u64 *small, const DevCtl *ctl, hipStream_t s, bool img_ready = false);
+/* true when launch_orthogonalize(rows) runs on the matrix cores, i.e. reads the coefficient image */
+bool ortho_uses_mfma(const KernelCfg &c, int64_t rows);
 
 /* *host_mapped <- *ctl, written by the GPU into host-mapped pinned memory (no copy engine involved) */
 hipError_t launch_publish_ctl(const DevCtl *ctl, DevCtl *host_mapped, hipStream_t s);
@@ -126,14 +134,15 @@ hipError_t launch_publish_ctl(const DevCtl *ctl, DevCtl *host_mapped, hipStream_
 /* device-to-device copy by a streaming kernel (HBM speed) */
 hipError_t launch_copy(const KernelCfg &c, void *dst, const void *src, size_t bytes, hipStream_t s);
 
-/* X[i] <- X[i] mod p for 64-bit words that hold sums of a few residues (after a reduce-scatter) */
-hipError_t launch_reduce_modp(const KernelCfg &c, void *X, int64_t words, const DevCtl *ctl, hipStream_t s);
+/* dst[i] <- src[i] mod p for 64-bit words that hold sums of a few residues (the landing place of a reduce-scatter);
+ * a no-op once the stop flag is up, so dst keeps the residues of the last real iteration */
+hipError_t launch_reduce_modp(const KernelCfg &c, void *dst, const void *src, int64_t words, const DevCtl *ctl, hipStream_t s);
 
 /* the same update on v_mfma_i32_16x16x64_i8 (blz_dense_mfma.hip): exact integer contractions of base-256 digits */
 size_t ortho_mfma_image_bytes(void);
 bool ortho_mfma_supported(const KernelCfg &c);
 hipError_t launch_orthogonalize_mfma(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows, const u64 *small,
-				     const DevCtl *ctl, hipStream_t s);
+				     const DevCtl *ctl, hipStream_t s, bool img_ready);
 
 /* block_dot_products on the matrix cores (p = 2^61-1, n = 8 / 16): same partial rows as launch_block_dot */
 bool block_dot_mfma_supported(const KernelCfg &c);

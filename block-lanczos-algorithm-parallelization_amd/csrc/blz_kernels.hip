@@ -8,6 +8,7 @@
  * Citations are relative to /root/reference/.
  */
 #include "blz_kernels.h"
+#include "ortho_img.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -1224,8 +1225,8 @@ static void staged_launch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y,
 	/* gathers in flight per lane: 8 where a wavefront holds few lane groups (G >= 16) or the registers allow (the
 	 * plain form at G = 8), else 4; BLZ_STAGE_U overrides between the two where both exist */
 	bool deep = G >= 16 || (G == 8 && !DOT && A.st_deep);
-	if (const char *e = getenv("BLZ_STAGE_U"))
-		deep = atoi(e) >= 8;
+	if (c.stage_u > 0)
+		deep = c.stage_u >= 8;
 #define STAGED_GO(UU)                                                                                                   \
 	hipLaunchKernelGGL((k_spmv_staged<W, G, MERS, DOT, VALS, UU>), dim3((unsigned)blocks), dim3(BLOCK), lds, s, A.row_ptr, \
 			   (const u32 *)A.col_idx, A.val, A.palette, X, Y, Vd, (long long)A.rows, c.n, A.st_rpg, A.st_capw, accum, \
@@ -1604,42 +1605,60 @@ hipError_t launch_block_dot(const KernelCfg &c, const void *V, const void *AV, i
 			    : dot_dispatch<u64, 0>(c, (const u64 *)V, (const u64 *)AV, rows, partial, max_blocks, nblocks, ctl, s);
 }
 
-/* out[e] = sum_b partial[b][e] mod p: one wavefront per output word. */
-__global__ void __launch_bounds__(BLOCK)
-k_dot_finalize(const u64 *__restrict__ partial, int nblocks, int words, u64 p, u64 *__restrict__ out,
+/*
+ * out[e] = sum_b partial[b][e] mod p.  A workgroup of 16 wavefronts owns CW = min(8, words) adjacent output words; a lane is
+ * (row lane, word): one load instruction of a wavefront covers 64 / CW partial rows x CW words (64-byte pieces of the
+ * rows instead of one word out of 64 different lines), the 16 wavefronts take interleaved sets of rows, so for the ~1000
+ * partial rows of the fused SpMV every lane has 8 loads, all in flight at once.  Row lanes are added across the
+ * wavefront, wavefronts through LDS.  (Round 2: one wavefront per word, lanes over rows: 6.2 us on the GL7d19 shape.)
+ */
+#define FIN_THREADS 1024
+__global__ void __launch_bounds__(FIN_THREADS)
+k_dot_finalize(const u64 *__restrict__ partial, int nblocks, int words, int cw_log2, u64 p, u64 *__restrict__ out,
 	       const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
-	const int e = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-	if (e >= words)
-		return;
+	__shared__ u64 part[FIN_THREADS / 64][8];
+	const int CW = 1 << cw_log2, RL = 64 >> cw_log2;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wl = lane & (CW - 1), rl = lane >> cw_log2;
+	const int e = blockIdx.x * CW + wl, step = (FIN_THREADS / 64) * RL;
 	u64 s = 0;
-	int b = lane;
-	for (; b + 7 * 64 < nblocks; b += 8 * 64) {	/* eight independent loads in flight, then the adds */
+	int b = wave * RL + rl;
+	for (; b + 7 * step < nblocks; b += 8 * step) {	/* eight independent loads in flight, then the adds */
 		u64 x[8];
 #pragma unroll
 		for (int q = 0; q < 8; q++)
-			x[q] = partial[(size_t)(b + q * 64) * words + e];
+			x[q] = partial[(size_t)(b + q * step) * words + e];
 #pragma unroll
 		for (int q = 0; q < 8; q++)
 			s = addmod(s, x[q], p);
 	}
-	for (; b < nblocks; b += 64)
+	for (; b < nblocks; b += step)
 		s = addmod(s, partial[(size_t)b * words + e], p);
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1)
+	for (int off = 32; off >= CW; off >>= 1)
 		s = addmod(s, shfl_xor64(s, off), p);
-	if (lane == 0)
-		out[e] = s;
+	if (lane < CW)
+		part[wave][lane] = s;
+	__syncthreads();
+	if (threadIdx.x < CW) {
+		u64 t = 0;
+#pragma unroll
+		for (int w = 0; w < FIN_THREADS / 64; w++)
+			t = addmod(t, part[w][threadIdx.x], p);
+		out[e] = t;
+	}
 }
 
 hipError_t launch_dot_finalize(const KernelCfg &c, const u64 *partial, int nblocks, u64 *out, const DevCtl *ctl,
 			       hipStream_t s)
 {
-	const int words = 2 * c.n * c.n;
-	const int blocks = (words * 64 + BLOCK - 1) / BLOCK;
-	hipLaunchKernelGGL(k_dot_finalize, dim3(blocks), dim3(BLOCK), 0, s, partial, nblocks, words, c.m.p, out, ctl);
+	const int words = 2 * c.n * c.n;	/* a power of two times 2: 2, 8, 18 (n = 3, unpadded) ...: CW must divide it */
+	int cw_log2 = 3;
+	while ((words & ((1 << cw_log2) - 1)) != 0)
+		cw_log2--;
+	hipLaunchKernelGGL(k_dot_finalize, dim3(words >> cw_log2), dim3(FIN_THREADS), 0, s, partial, nblocks, words, cw_log2, c.m.p, out,
+			   ctl);
 	return hipGetLastError();
 }
 
@@ -1792,11 +1811,17 @@ __device__ static int ff_sweep(u64 *A, u64 *Wm, u64 *S, int n, int G, const ModP
 /*
  * semi_inverse(), sequential/lanczos_modp.c:342-438, plus the two n x n coefficient matrices that
  * orthogonalize() derives from it (:460-475), so that the row kernel only streams.
- * small = [vtAv | vtAAv | winv | d | c | vtAvd].  One wavefront.
+ * small = [vtAv | vtAAv | winv | d | c | vtAvd].  One workgroup.
+ * `sums` = where vtAv | vtAAv come from: `small` itself, or the landing place of the all-reduce over the ranks (sums of
+ * residues); `small` receives their residues, and only if the stop flag is down -- the iterations a batch enqueues past
+ * the stop run the all-reduce again, and `small` must stay what the last real iteration left (round 3).
+ * IMGN = 16: the kernel also builds the coefficient image of the matrix-core block update (ortho_img.h) from the
+ * coefficients it has just computed: one launch where round 2 had two (k_ortho_mfma_prep).
  */
-template <int MERS>
+template <int MERS, int IMGN>
 __global__ void __launch_bounds__(1024)
-k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, ModP m, int in_loop)
+k_semi_inverse(const u64 *__restrict__ sums, u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, ModP m, int in_loop,
+	       unsigned char *__restrict__ img)
 {
 	/* in_loop = 0: stand-alone call (blz_semi_inverse): neither obeys nor sets the sticky stop flag */
 	if (in_loop && ctl->stop)
@@ -1804,13 +1829,14 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	const int nn = n * n;
 	u64 *A = (u64 *)smem_raw, *Wm = A + nn, *S = Wm + nn, *Pre = S + n;
+	u64 *coef = Pre + n;			/* IMGN: the six-panel layout of `small`, panels winv, c, vtAvd filled */
 	const int lane = threadIdx.x, T = (int)blockDim.x;
 	u64 *vtAv = small, *vtAAv = small + nn, *winv = small + 2 * nn, *dvec = small + 3 * nn;
 	u64 *cmat = small + 4 * nn, *vtAvd = small + 5 * nn;
 
 	/* inputs may be sums of per-rank residues: bring them back into [0,p) */
 	for (int e = lane; e < nn; e += T) {
-		const u64 x = reduce128<MERS>(0, vtAv[e], m), y = reduce128<MERS>(0, vtAAv[e], m);
+		const u64 x = reduce128<MERS>(0, sums[e], m), y = reduce128<MERS>(0, sums[nn + e], m);
 		vtAv[e] = x;
 		vtAAv[e] = y;
 		A[e] = x;
@@ -1847,6 +1873,8 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, 
 		const u64 w = mulmod<MERS>(Wm[e], S[e / n], m);
 		Wm[e] = w;
 		winv[e] = w;
+		if (IMGN)
+			coef[2 * nn + e] = w;
 	}
 	if (lane < n)
 		dvec[lane] = (dbits >> lane) & 1;
@@ -1867,9 +1895,15 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, 
 			}
 		}
 		const u64 r = acc_reduce<MERS>(acc, m);
-		cmat[e] = r ? m.p - r : 0;
+		const u64 ce = r ? m.p - r : 0;
+		cmat[e] = ce;
 		const u64 x = vtAv[e];
-		vtAvd[e] = (dj && x) ? m.p - x : 0;
+		const u64 ve = (dj && x) ? m.p - x : 0;
+		vtAvd[e] = ve;
+		if (IMGN) {
+			coef[4 * nn + e] = ce;
+			coef[5 * nn + e] = ve;
+		}
 	}
 	if (lane == 0) {
 		ctl->npiv = npiv;
@@ -1880,13 +1914,62 @@ k_semi_inverse(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, int G, 
 				ctl->iterations += 1;
 		}
 	}
+	if constexpr (IMGN == 16) {
+		/* (the image of an iteration that stops is never read: every later kernel is a no-op) */
+		__syncthreads();
+		ortho_image_build<16>(coef, img, (int *)(coef + 6 * nn), lane, T);
+	}
+}
+
+/* 64-bit read of a lane that is the same for the whole wavefront: two v_readlane_b32, no LDS crossbar round trip */
+MODP_DEV u64 readlane64(u64 x, int lane)
+{
+	const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x, lane), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), lane);
+	return ((u64)hi << 32) | lo;
+}
+
+/* lane (i, k) of the (rows x 2^LG) lane grid reads lane (i, K): a VALU move with a DPP modifier (row_newbcast inside the
+ * 16-lane DPP row for groups of 8, quad_perm for groups of 4 and 2), no LDS crossbar */
+template <int K, int LG>
+MODP_DEV u32 col_bcast32(u32 x)
+{
+	if constexpr (LG == 3)
+		return group_bcast32<K & 7, 8>(x);
+	else if constexpr (LG == 2)
+		return (u32)__builtin_amdgcn_update_dpp(0, (int)x, (K & 3) * 0x55, 0xF, 0xF, false);
+	else if constexpr (LG == 1)
+		return (u32)__builtin_amdgcn_update_dpp(0, (int)x, (K & 1) * 0x05 + (2 + (K & 1)) * 0x50, 0xF, 0xF, false);
+	else
+		return x;
+}
+
+template <int K, int LG>
+MODP_DEV u64 col_bcast(u64 x)
+{
+	return ((u64)col_bcast32<K, LG>((u32)(x >> 32)) << 32) | col_bcast32<K, LG>((u32)x);
+}
+
+/* the same with the column picked at run time (uniform over the wavefront: a scalar branch) */
+template <int LG>
+MODP_DEV u64 col_bcast_at(u64 x, int j)
+{
+	constexpr int G = 1 << LG;
+	u64 r = x;
+	static_for<0, G>([&](auto kc) {
+		constexpr int K = decltype(kc)::value;
+		if (j == K)
+			r = col_bcast<K, LG>(x);
+	});
+	return r;
 }
 
 /*
  * Register-resident form for n*n <= 64 (n <= 8): lane (i,k) = (lane >> LG, lane & (G-1)) of the single wavefront
  * holds A[i][k], W[i][k] and the scalar of row i; pivot search is one ballot, row swaps / broadcasts are cross-lane
- * reads.  No LDS round trips: the serial chain per column is three shuffles and two MACs.  Same fraction-free
- * sweep, same pivot rule, same single inversion as k_semi_inverse.
+ * reads.  No LDS round trips: the serial chain per column is one crossbar read and two MACs (round 3: the pivot comes
+ * by v_readlane, the multiplier of a row by a DPP move, and rows are only exchanged when the pivot is not on the
+ * diagonal -- almost never mod a large prime).  Same fraction-free sweep, same pivot rule, same single inversion as
+ * k_semi_inverse.
  */
 template <int MERS, int LG>
 __device__ static int ff_sweep_reg(u64 &a, u64 *w, u64 *s, int n, const ModP &m, u64 *mask)
@@ -1903,16 +1986,18 @@ __device__ static int ff_sweep_reg(u64 &a, u64 *w, u64 *s, int n, const ModP &m,
 		const int piv = (__ffsll(cand) - 1) >> LG;
 		bits |= 1ull << j;
 		found++;
-		const int from = ((i == j ? piv : (i == piv ? j : i)) << LG) + k;	/* swap rows piv <-> j */
-		a = shfl64(a, from);
-		if (w)
-			*w = shfl64(*w, from);
-		if (s)
-			*s = shfl64(*s, from);
-		const u64 pv = shfl64(a, (j << LG) + j);
+		if (piv != j) {		/* swap rows piv <-> j */
+			const int from = ((i == j ? piv : (i == piv ? j : i)) << LG) + k;
+			a = shfl64(a, from);
+			if (w)
+				*w = shfl64(*w, from);
+			if (s)
+				*s = shfl64(*s, from);
+		}
+		const u64 pv = readlane64(a, (j << LG) + j);
 		if (s && i == j)
 			*s = pv;
-		const u64 mult = shfl64(a, (i << LG) + j), y = shfl64(a, (j << LG) + k);
+		const u64 mult = col_bcast_at<LG>(a, j), y = shfl64(a, (j << LG) + k);
 		const u64 wy = w ? shfl64(*w, (j << LG) + k) : 0;
 		if (valid && i != j && mult != 0) {
 			const u64 neg = m.p - mult;
@@ -1937,99 +2022,119 @@ __device__ static int ff_sweep_reg(u64 &a, u64 *w, u64 *s, int n, const ModP &m,
 	return found;
 }
 
-template <int MERS, int LG>
-__global__ void __launch_bounds__(64)
-k_semi_inverse_reg(u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, ModP m, int in_loop)
+/* IMG: n = 8, p = 2^61 - 1: three more wavefronts wait at a barrier while wavefront 0 runs the sweep, then all four build
+ * the coefficient image of the matrix-core block update from the coefficients wavefront 0 left in LDS. */
+template <int MERS, int LG, bool IMG>
+__global__ void __launch_bounds__(IMG ? 256 : 64)
+k_semi_inverse_reg(const u64 *__restrict__ sums, u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, ModP m, int in_loop,
+		   unsigned char *__restrict__ img)
 {
-	if (in_loop && ctl->stop)
-		return;
 	constexpr int G = 1 << LG;
-	const int nn = n * n, lane = threadIdx.x, i = lane >> LG, k = lane & (G - 1);
-	const bool valid = i < n && k < n;
+	const int nn = n * n, lane = threadIdx.x, i = (lane & 63) >> LG, k = lane & (G - 1);
+	const bool valid = lane < 64 && i < n && k < n;
 	const int e = valid ? i * n + k : 0;
-	u64 *vtAv = small, *vtAAv = small + nn, *winv = small + 2 * nn, *dvec = small + 3 * nn;
-	u64 *cmat = small + 4 * nn, *vtAvd = small + 5 * nn;
-	/* inputs may be sums of per-rank residues: bring them back into [0,p) */
-	const u64 x0 = valid ? reduce128<MERS>(0, vtAv[e], m) : 0, y0 = valid ? reduce128<MERS>(0, vtAAv[e], m) : 0;
-	if (valid) {
-		vtAv[e] = x0;
-		vtAAv[e] = y0;
-	}
-	u64 sel = 0, dbits = 0;
-	u64 a = x0;
-	ff_sweep_reg<MERS, LG>(a, nullptr, nullptr, n, m, &sel);			/* phase 1, :349-382 */
-	const bool both = valid && ((sel >> i) & 1) && ((sel >> k) & 1);
-	a = both ? x0 : 0;								/* :384-388 */
-	u64 w = (valid && i == k && ((sel >> i) & 1)) ? 1 : 0, s = 1;
-	const int npiv = ff_sweep_reg<MERS, LG>(a, &w, &s, n, m, &dbits);		/* phase 2, :389-436 */
-	/* one inversion for all row scalars: prefix products, then walk back (uniform over the wavefront) */
-	u64 pre[G], run = 1;
-#pragma unroll
-	for (int r = 0; r < G; r++) {
-		const u64 sr = shfl64(s, r << LG);
-		if (r < n)
-			run = mulmod<MERS>(run, sr, m);
-		pre[r] = run;
-	}
-	u64 inv = dev_invmod_any<MERS>(run, m), mine = 0;
-#pragma unroll
-	for (int r = G - 1; r >= 0; r--) {
-		const u64 sr = shfl64(s, r << LG);
-		if (r < n) {
-			const u64 ir = r ? mulmod<MERS>(inv, pre[r - 1], m) : inv;
-			if (r == i)
-				mine = ir;
-			inv = mulmod<MERS>(inv, sr, m);
+	/* the three loads go out together; the flag is looked at when they are back */
+	const int stop = in_loop ? ctl->stop : 0;
+	const u64 xr = sums[e], yr = sums[nn + e];
+	if (stop)
+		return;
+	__shared__ u64 coef[IMG ? 6 * 64 : 1];
+	__shared__ int init_sh[IMG ? OG<8>::NE : 1];
+	if (lane < 64) {
+		u64 *vtAv = small, *vtAAv = small + nn, *winv = small + 2 * nn, *dvec = small + 3 * nn;
+		u64 *cmat = small + 4 * nn, *vtAvd = small + 5 * nn;
+		/* inputs may be sums of per-rank residues: bring them back into [0,p) */
+		const u64 x0 = valid ? reduce128<MERS>(0, xr, m) : 0, y0 = valid ? reduce128<MERS>(0, yr, m) : 0;
+		if (valid) {
+			vtAv[e] = x0;
+			vtAAv[e] = y0;
 		}
-	}
-	const u64 wn = valid ? mulmod<MERS>(w, mine, m) : 0;
-	if (valid)
-		winv[e] = wn;
-	if (lane < n)
-		dvec[lane] = (dbits >> lane) & 1;
-	/* c = -(winv * spliced), vtAvd = -vtAv on the selected columns (:462-475), canonical; lane (i,k) owns c[i][k] */
-	const bool dk = (dbits >> k) & 1;
-	const u64 sp = dk ? y0 : x0;						/* spliced[i][k] */
-	Acc acc;
-	acc_zero(acc);
-	u32 cnt = 0;
+		u64 sel = 0, dbits = 0;
+		u64 a = x0;
+		ff_sweep_reg<MERS, LG>(a, nullptr, nullptr, n, m, &sel);			/* phase 1, :349-382 */
+		const bool both = valid && ((sel >> i) & 1) && ((sel >> k) & 1);
+		a = both ? x0 : 0;								/* :384-388 */
+		u64 w = (valid && i == k && ((sel >> i) & 1)) ? 1 : 0, s = 1;
+		const int npiv = ff_sweep_reg<MERS, LG>(a, &w, &s, n, m, &dbits);		/* phase 2, :389-436 */
+		/* one inversion for all row scalars: the lanes of row i multiply the OTHER rows' scalars (q), q * s_i is the product
+		 * of all of them -- the same in every lane --, and 1 / s_i = q / (that product): n + 2 products around the
+		 * inversion where the prefix walk had 3 n */
+		u64 q = 1;
 #pragma unroll
-	for (int q = 0; q < G; q++) {
-		const u64 wiq = shfl64(wn, (i << LG) + q), sqk = shfl64(sp, (q << LG) + k);
-		if (q < n) {
-			acc_mac64(acc, wiq, sqk);
-			if (++cnt == m.chunk) {
-				cnt = 0;
-				acc_set(acc, acc_reduce<MERS>(acc, m));
+		for (int r = 0; r < G; r++) {
+			const u64 sr = readlane64(s, r << LG);
+			if (r < n) {
+				const u64 t = mulmod<MERS>(q, sr, m);
+				q = r == i ? q : t;
+			}
+		}
+		const u64 all = readlane64(mulmod<MERS>(q, s, m), 0);
+		const u64 mine = mulmod<MERS>(dev_invmod_any<MERS>(all, m), q, m);
+		const u64 wn = valid ? mulmod<MERS>(w, mine, m) : 0;
+		if (valid)
+			winv[e] = wn;
+		if (lane < n)
+			dvec[lane] = (dbits >> lane) & 1;
+		/* c = -(winv * spliced), vtAvd = -vtAv on the selected columns (:462-475), canonical; lane (i,k) owns c[i][k] */
+		const bool dk = (dbits >> k) & 1;
+		const u64 sp = dk ? y0 : x0;						/* spliced[i][k] */
+		Acc acc;
+		acc_zero(acc);
+		u32 cnt = 0;
+		static_for<0, G>([&](auto qc) {
+			constexpr int Q = decltype(qc)::value;
+			const u64 wiq = col_bcast<Q, LG>(wn), sqk = shfl64(sp, (Q << LG) + k);
+			if (Q < n) {
+				acc_mac64(acc, wiq, sqk);
+				if (++cnt == m.chunk) {
+					cnt = 0;
+					acc_set(acc, acc_reduce<MERS>(acc, m));
+				}
+			}
+		});
+		u64 ce = 0, ve = 0;
+		if (valid) {
+			const u64 r = acc_reduce<MERS>(acc, m);
+			ce = r ? m.p - r : 0;
+			ve = (dk && x0) ? m.p - x0 : 0;
+			cmat[e] = ce;
+			vtAvd[e] = ve;
+		}
+		if (IMG) {		/* n = 8 = G: e = lane */
+			coef[2 * 64 + lane] = wn;
+			coef[4 * 64 + lane] = ce;
+			coef[5 * 64 + lane] = ve;
+		}
+		if (lane == 0) {
+			ctl->npiv = npiv;
+			if (in_loop) {
+				if (npiv == 0)
+					ctl->stop = 1;
+				else
+					ctl->iterations += 1;
 			}
 		}
 	}
-	if (valid) {
-		const u64 r = acc_reduce<MERS>(acc, m);
-		cmat[e] = r ? m.p - r : 0;
-		vtAvd[e] = (dk && x0) ? m.p - x0 : 0;
-	}
-	if (lane == 0) {
-		ctl->npiv = npiv;
-		if (in_loop) {
-			if (npiv == 0)
-				ctl->stop = 1;
-			else
-				ctl->iterations += 1;
-		}
+	if constexpr (IMG) {
+		__syncthreads();
+		ortho_image_build<8>(coef, img, init_sh, lane, 256);
 	}
 }
 
-hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int in_loop, hipStream_t s)
+hipError_t launch_semi_inverse(const KernelCfg &c, const u64 *sums, u64 *small, DevCtl *ctl, int in_loop, int build_img,
+			       hipStream_t s)
 {
 	int G = 1, LG = 0;
 	while (G < c.n) {
 		G <<= 1;
 		LG++;
 	}
+	unsigned char *img = (unsigned char *)c.mfma_img;
+	if (build_img && !(ortho_mfma_supported(c) && img))
+		return hipErrorInvalidValue;
 	if (c.n <= 8) {		/* the whole n x n problem fits one wavefront's registers */
 #define SEMI_REG(MM, LL)                                                                                          \
-	hipLaunchKernelGGL((k_semi_inverse_reg<MM, LL>), dim3(1), dim3(64), 0, s, small, ctl, c.n, c.m, in_loop)
+	hipLaunchKernelGGL((k_semi_inverse_reg<MM, LL, false>), dim3(1), dim3(64), 0, s, sums, small, ctl, c.n, c.m, in_loop, img)
 #define SEMI_REG_LG(MM)                                                                                           \
 	do {                                                                                                      \
 		if (LG == 0) SEMI_REG(MM, 0);                                                                     \
@@ -2037,7 +2142,10 @@ hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int 
 		else if (LG == 2) SEMI_REG(MM, 2);                                                                \
 		else SEMI_REG(MM, 3);                                                                             \
 	} while (0)
-		if (c.mers == 61)
+		if (build_img)		/* n = 8, p = 2^61 - 1 (ortho_mfma_supported) */
+			hipLaunchKernelGGL((k_semi_inverse_reg<61, 3, true>), dim3(1), dim3(256), 0, s, sums, small, ctl, c.n, c.m, in_loop,
+					   img);
+		else if (c.mers == 61)
 			SEMI_REG_LG(61);
 		else if (c.mers == 31)
 			SEMI_REG_LG(31);
@@ -2047,22 +2155,26 @@ hipError_t launch_semi_inverse(const KernelCfg &c, u64 *small, DevCtl *ctl, int 
 #undef SEMI_REG
 		return hipGetLastError();
 	}
-	const size_t lds = ((size_t)2 * c.n * c.n + 2 * c.n) * sizeof(u64);
+	size_t lds = ((size_t)2 * c.n * c.n + 2 * c.n) * sizeof(u64);
 	/* one thread per matrix entry up to a full workgroup: every elimination step is then one pass (n = 64: four) */
-	const int threads = G * G > 1024 ? 1024 : (G * G < 64 ? 64 : G * G);
-#define SEMI(MM)                                                                                                   \
+	int threads = G * G > 1024 ? 1024 : (G * G < 64 ? 64 : G * G);
+#define SEMI(MM, II)                                                                                               \
 	do {                                                                                                       \
 		if (lds > 48 * 1024)                                                                               \
-			hipFuncSetAttribute((const void *)k_semi_inverse<MM>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+			hipFuncSetAttribute((const void *)k_semi_inverse<MM, II>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
 					    (int)lds);                                                             \
-		hipLaunchKernelGGL((k_semi_inverse<MM>), dim3(1), dim3(threads), lds, s, small, ctl, c.n, G, c.m, in_loop); \
+		hipLaunchKernelGGL((k_semi_inverse<MM, II>), dim3(1), dim3(threads), lds, s, sums, small, ctl, c.n, G, c.m, in_loop, img); \
 	} while (0)
-	if (c.mers == 61)
-		SEMI(61);
+	if (build_img) {	/* n = 16, p = 2^61 - 1: all 16 wavefronts for the 49 KB image */
+		lds += (size_t)6 * c.n * c.n * sizeof(u64) + OG<16>::NE * sizeof(int);
+		threads = 1024;
+		SEMI(61, 16);
+	} else if (c.mers == 61)
+		SEMI(61, 0);
 	else if (c.mers == 31)
-		SEMI(31);
+		SEMI(31, 0);
 	else
-		SEMI(0);
+		SEMI(0, 0);
 #undef SEMI
 	return hipGetLastError();
 }
@@ -2376,11 +2488,16 @@ static hipError_t ortho_dispatch(const KernelCfg &c, W *V, const W *AV, W *P, in
 	return hipGetLastError();
 }
 
-hipError_t launch_orthogonalize(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows,
-				const u64 *small, const DevCtl *ctl, hipStream_t s)
+bool ortho_uses_mfma(const KernelCfg &c, int64_t rows)
 {
-	if (ortho_mfma_supported(c) && rows >= c.mfma_min_rows)
-		return launch_orthogonalize_mfma(c, V, AV, P, rows, small, ctl, s);
+	return ortho_mfma_supported(c) && rows >= c.mfma_min_rows && rows > 0;
+}
+
+hipError_t launch_orthogonalize(const KernelCfg &c, void *V, const void *AV, void *P, int64_t rows,
+				const u64 *small, const DevCtl *ctl, hipStream_t s, bool img_ready)
+{
+	if (ortho_uses_mfma(c, rows))
+		return launch_orthogonalize_mfma(c, V, AV, P, rows, small, ctl, s, img_ready);
 	if (c.word == 4)
 		return c.mers == 31 ? ortho_dispatch<u32, 31>(c, (u32 *)V, (const u32 *)AV, (u32 *)P, rows, small, ctl, s)
 				    : ortho_dispatch<u32, 0>(c, (u32 *)V, (const u32 *)AV, (u32 *)P, rows, small, ctl, s);
@@ -2438,27 +2555,30 @@ hipError_t launch_copy(const KernelCfg &c, void *dst, const void *src, size_t by
 }
 
 /* x <- x mod p, words that are sums of a few residues (the reduce-scatter of partial products) */
+/* Out of place, and a no-op after the stop: the collective that fills `src` is enqueued by the host whatever the flag
+ * says, and past the stop it sums stale partial products -- dst must keep the last real iteration's residues (a batch
+ * always runs past the stop: blz_final_check reads TMP). */
 template <int MERS>
 __global__ void __launch_bounds__(BLOCK)
-k_reduce_modp(u64 *__restrict__ x, long long words, ModP m, const DevCtl *__restrict__ ctl)
+k_reduce_modp(u64 *__restrict__ dst, const u64 *__restrict__ src, long long words, ModP m, const DevCtl *__restrict__ ctl)
 {
 	if (ctl->stop)
 		return;
 	const long long step = (long long)gridDim.x * BLOCK;
 	for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < words; i += step)
-		x[i] = reduce128<MERS>(0, x[i], m);
+		dst[i] = reduce128<MERS>(0, src[i], m);
 }
 
-hipError_t launch_reduce_modp(const KernelCfg &c, void *X, int64_t words, const DevCtl *ctl, hipStream_t s)
+hipError_t launch_reduce_modp(const KernelCfg &c, void *X, const void *S, int64_t words, const DevCtl *ctl, hipStream_t s)
 {
-	if (words <= 0 || c.word != 8)
-		return c.word == 8 ? hipSuccess : hipErrorInvalidValue;
+	if (words <= 0)		/* (64-bit words whatever the residue width: the callers' buffers hold u64 sums) */
+		return hipSuccess;
 	long long blocks = (words + BLOCK * 4 - 1) / (BLOCK * 4);
 	blocks = blocks < 1 ? 1 : (blocks > (long long)c.num_cu * 8 ? (long long)c.num_cu * 8 : blocks);
 	if (c.mers == 61)
-		hipLaunchKernelGGL((k_reduce_modp<61>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (u64 *)X, (long long)words, c.m, ctl);
+		hipLaunchKernelGGL((k_reduce_modp<61>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (u64 *)X, (const u64 *)S, (long long)words, c.m, ctl);
 	else
-		hipLaunchKernelGGL((k_reduce_modp<0>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (u64 *)X, (long long)words, c.m, ctl);
+		hipLaunchKernelGGL((k_reduce_modp<0>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (u64 *)X, (const u64 *)S, (long long)words, c.m, ctl);
 	return hipGetLastError();
 }
 

@@ -367,6 +367,128 @@ int blz_synth_coo(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int 
 }
 
 /*
+ * The entries of blz_synth_coo's matrix (same shape, seed, values) that fall in rows [r0, r1) AND columns [c0, c1), with
+ * their GLOBAL indices, rows ascending -- without ever holding the rest: every row is seeded by itself, so a rank of a
+ * sharded solve can make its own rows (c0 = 0, c1 = ncols) and its own columns (r0 = 0, r1 = nrows) of config 5's
+ * 50 M x 50 M / 2e9-entry matrix from 1/8 of the memory.  The reference's MPI loader hands out pieces of
+ * the file the same way (mpi/lanczos_modp.c:1841-1845).  One pass: every thread keeps the wanted entries of a
+ * contiguous range of rows in its own buffers, which are then laid end to end.
+ */
+int blz_synth_coo_part(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int pattern, uint64_t prime,
+		       int64_t r0, int64_t r1, int64_t c0, int64_t c1, blz_coo *out)
+{
+	static const int32_t palette[7] = { 1, 1, 1, 2, 3, -1, -2 };
+	if (!out || nrows <= 0 || ncols <= 0 || nnz < 0 || prime < 2 || nrows > INT32_MAX || ncols > INT32_MAX ||
+	    r0 < 0 || r1 < r0 || r1 > nrows || c0 < 0 || c1 < c0 || c1 > ncols)
+		return blz_fail(BLZ_EINVAL, "blz_synth_coo_part: bad shape or range");
+	const int64_t base = nnz / nrows, extra = nnz % nrows;
+	if (base + (extra ? 1 : 0) > ncols || base + 1 > 4096)
+		return blz_fail(BLZ_EINVAL, "blz_synth_coo_part: rows too long");
+	memset(out, 0, sizeof *out);
+	out->nrows = nrows;
+	out->ncols = ncols;
+	const int nth = omp_get_max_threads();
+	int32_t **bi = calloc((size_t)nth, sizeof *bi), **bj = calloc((size_t)nth, sizeof *bj);
+	uint32_t **bx = calloc((size_t)nth, sizeof *bx);
+	int64_t *cnt = calloc((size_t)nth + 1, sizeof *cnt);
+	int fail = !bi || !bj || !bx || !cnt;
+	const int all_cols = c0 == 0 && c1 == ncols;
+	if (!fail) {
+#pragma omp parallel num_threads(nth)
+		{
+			const int t = omp_get_thread_num(), T = omp_get_num_threads();
+			const int64_t span = r1 - r0, a = r0 + span * t / T, b = r0 + span * (t + 1) / T;
+			/* expected share, with room; grown when it runs out */
+			int64_t cap = (int64_t)((double)(b - a) * (double)(base + 1) * ((double)(c1 - c0) / (double)ncols) * 1.05) + 1024;
+			int32_t *ti = malloc(sizeof *ti * (size_t)cap), *tj = malloc(sizeof *tj * (size_t)cap);
+			uint32_t *tx = malloc(sizeof *tx * (size_t)cap);
+			int64_t have = 0;
+			int bad = !ti || !tj || !tx;
+			int32_t row[4097];
+			for (int64_t r = a; r < b && !bad; r++) {
+				const int64_t n_r = base + (r < extra);
+				uint64_t sd = seed ^ ((uint64_t)r * 0xD1342543DE82EF95ull);
+				if (have + n_r > cap) {
+					cap = cap + cap / 4 + n_r;
+					int32_t *ni = realloc(ti, sizeof *ti * (size_t)cap), *nj = realloc(tj, sizeof *tj * (size_t)cap);
+					uint32_t *nx = realloc(tx, sizeof *tx * (size_t)cap);
+					ti = ni ? ni : ti;
+					tj = nj ? nj : tj;
+					tx = nx ? nx : tx;
+					if (!ni || !nj || !nx) {
+						bad = 1;
+						break;
+					}
+				}
+				for (int64_t k = 0; k < n_r; k++) {
+					int32_t col;
+					for (;;) {	/* distinct columns within the row: the draws of blz_synth_coo, in its order */
+						col = (int32_t)(splitmix64(&sd) % (uint64_t)ncols);
+						int dup = 0;
+						for (int64_t q = 0; q < k && !dup; q++)
+							dup = (row[q] == col);
+						if (!dup)
+							break;
+					}
+					row[k] = col;
+					const int32_t v = pattern ? 1 : palette[splitmix64(&sd) % 7];
+					if (all_cols || (col >= c0 && col < c1)) {
+						ti[have] = (int32_t)r;
+						tj[have] = col;
+						tx[have] = (uint32_t)((uint64_t)(uint32_t)v % prime);
+						have++;
+					}
+				}
+			}
+			bi[t] = ti;
+			bj[t] = tj;
+			bx[t] = tx;
+			cnt[t + 1] = have;
+			if (bad) {
+#pragma omp atomic write
+				fail = 1;
+			}
+		}
+	}
+	int rc = BLZ_OK;
+	if (fail) {
+		rc = blz_fail(BLZ_ENOMEM, "blz_synth_coo_part: out of memory");
+	} else {
+		for (int t = 0; t < nth; t++)
+			cnt[t + 1] += cnt[t];
+		const int64_t total = cnt[nth];
+		out->nnz = total;
+		out->i = malloc(sizeof *out->i * (size_t)(total ? total : 1));
+		out->j = malloc(sizeof *out->j * (size_t)(total ? total : 1));
+		out->x = malloc(sizeof *out->x * (size_t)(total ? total : 1));
+		if (!out->i || !out->j || !out->x) {
+			blz_coo_free(out);
+			rc = blz_fail(BLZ_ENOMEM, "blz_synth_coo_part: out of memory");
+		} else {
+#pragma omp parallel for schedule(static, 1)
+			for (int t = 0; t < nth; t++) {
+				const size_t m = (size_t)(cnt[t + 1] - cnt[t]);
+				if (m && bi[t]) {
+					memcpy(out->i + cnt[t], bi[t], m * sizeof *out->i);
+					memcpy(out->j + cnt[t], bj[t], m * sizeof *out->j);
+					memcpy(out->x + cnt[t], bx[t], m * sizeof *out->x);
+				}
+			}
+		}
+	}
+	for (int t = 0; t < nth; t++) {
+		if (bi) free(bi[t]);
+		if (bj) free(bj[t]);
+		if (bx) free(bx[t]);
+	}
+	free(bi);
+	free(bj);
+	free(bx);
+	free(cnt);
+	return rc;
+}
+
+/*
  * A matrix WITH structure, for the measurements the uniform stand-ins cannot make (it is never the headline workload):
  * the shape of a sieve relation matrix.  Row r gets floor(nnz/R) (+1) distinct columns,
  *   hot_pct  % drawn with probability ~ 1/(c + 16): heavy-tailed column degrees (small primes),
@@ -450,15 +572,32 @@ void blz_csr_free(blz_csr *A)
 /* Counting sort by row (or by column for the transpose); stable, so entries of one row keep
  * file order.  Order is irrelevant to the result: every output word is the canonical residue
  * of an exact integer sum. */
+/* rows [first, first + count) only (every entry of M must lie in them): the CSR's row q is row first + q */
+static int csr_from_coo_window(const blz_coo *M, int transpose, int pattern, int64_t first, int64_t count, blz_csr *out);
+
 int blz_csr_from_coo(const blz_coo *M, int transpose, int pattern, blz_csr *out)
 {
 	if (!M || !out)
 		return blz_fail(BLZ_EINVAL, "blz_csr_from_coo: bad argument");
+	return csr_from_coo_window(M, transpose, pattern, 0, transpose ? M->ncols : M->nrows, out);
+}
+
+static int csr_from_coo_window(const blz_coo *M, int transpose, int pattern, int64_t first, int64_t count, blz_csr *out)
+{
 	if (M->nnz >= (int64_t)UINT32_MAX)
 		return blz_fail(BLZ_EINVAL, "blz_csr_from_coo: nnz >= 2^32 per slab is not supported");
 	memset(out, 0, sizeof *out);
-	const int64_t rows = transpose ? M->ncols : M->nrows;
+	const int64_t rows = count;
 	const int32_t *ri = transpose ? M->j : M->i, *ci = transpose ? M->i : M->j;
+	{
+		int64_t outside = 0;
+#pragma omp parallel for schedule(static) reduction(+ : outside) if (M->nnz > 200000)
+		for (int64_t k = 0; k < M->nnz; k++)
+			outside += (ri[k] < first || ri[k] >= first + count);
+		if (outside)
+			return blz_fail(BLZ_EINVAL, "blz_csr_from_coo: %lld entries lie outside rows [%lld, %lld)", (long long)outside,
+					(long long)first, (long long)(first + count));
+	}
 	out->rows = rows;
 	out->cols = transpose ? M->nrows : M->ncols;
 	out->nnz = M->nnz;
@@ -483,7 +622,7 @@ int blz_csr_from_coo(const blz_coo *M, int transpose, int pattern, blz_csr *out)
 #pragma omp parallel for schedule(static) if (M->nnz > 200000)
 	for (int64_t k = 0; k < M->nnz; k++) {
 #pragma omp atomic update
-		next[ri[k] + 1]++;
+		next[ri[k] - first + 1]++;
 	}
 	for (int64_t r = 0; r < rows; r++)
 		next[r + 1] += next[r];		/* next[r] = start(r), next[rows] = nnz */
@@ -491,7 +630,7 @@ int blz_csr_from_coo(const blz_coo *M, int transpose, int pattern, blz_csr *out)
 	for (int64_t k = 0; k < M->nnz; k++) {
 		uint32_t at;
 #pragma omp atomic capture
-		at = next[ri[k]]++;
+		at = next[ri[k] - first]++;
 		out->col_idx[at] = ci[k];
 		if (out->val)
 			out->val[at] = M->x[k];
@@ -1209,6 +1348,7 @@ int blz_prepare(const blz_coo *M, int right, int nranks, int chunks, int reorder
 	P->right = right ? 1 : 0;
 	P->nranks = nranks;
 	P->chunks = chunks;
+	P->only_rank = -1;
 	P->locality[0] = P->locality[1] = 1.0;
 	int rc = BLZ_OK;
 	blz_coo R = *M;
@@ -1265,13 +1405,78 @@ int blz_prepare(const blz_coo *M, int right, int nranks, int chunks, int reorder
 	return BLZ_OK;
 }
 
+/*
+ * The prepared matrix of ONE rank, made from that rank's share alone: `row_part` = the entries of M in its rows
+ * [row_bounds[rank], row_bounds[rank+1]), `col_part` = the entries in its columns [col_bounds[rank], ...), both with
+ * global indices (blz_synth_coo_part makes them; a distributed loader would read them).  No process ever holds the
+ * whole matrix: config 5 (2e9 entries, 24 GB of triplets) costs each of 8 ranks 2 x 2.5e8 entries.  The partition
+ * is the caller's (bounds ascending from 0 to the dimension) and the numbering is kept -- a caller that wants the
+ * locality renumbering applies it before cutting.  The reference's MPI variant distributes the matrix the same way
+ * and never gathers it (mpi/lanczos_modp.c:1841-1900).  Not savable (blz_prepared_save refuses it).
+ */
+int blz_prepare_rank(const blz_coo *row_part, const blz_coo *col_part, int64_t nrows, int64_t ncols, int64_t nnz_total,
+		     int right, int rank, int nranks, int chunks, const int64_t *row_bounds, const int64_t *col_bounds,
+		     blz_prepared **out)
+{
+	if (!row_part || !col_part || !out || !row_bounds || !col_bounds || nranks < 1 || rank < 0 || rank >= nranks ||
+	    chunks < 1 || nrows <= 0 || ncols <= 0 || nrows > INT32_MAX || ncols > INT32_MAX)
+		return blz_fail(BLZ_EINVAL, "blz_prepare_rank: bad argument");
+	*out = NULL;
+	for (int g = 0; g < nranks; g++)
+		if (row_bounds[g] > row_bounds[g + 1] || col_bounds[g] > col_bounds[g + 1])
+			return blz_fail(BLZ_EINVAL, "blz_prepare_rank: bounds must ascend");
+	if (row_bounds[0] != 0 || col_bounds[0] != 0 || row_bounds[nranks] != nrows || col_bounds[nranks] != ncols)
+		return blz_fail(BLZ_EINVAL, "blz_prepare_rank: bounds must run from 0 to the dimension");
+	blz_prepared *P = calloc(1, sizeof *P);
+	if (!P)
+		return blz_fail(BLZ_ENOMEM, "blz_prepare_rank: out of memory");
+	P->nrows = nrows;
+	P->ncols = ncols;
+	P->nnz = nnz_total;
+	P->right = right ? 1 : 0;
+	P->nranks = nranks;
+	P->chunks = chunks;
+	P->only_rank = rank;
+	P->locality[0] = P->locality[1] = 1.0;
+	int rc = BLZ_OK;
+	for (int t = 0; t < 2 && rc == BLZ_OK; t++) {
+		const int sd = t == 0 ? (right ? 1 : 0) : (right ? 0 : 1);
+		const int64_t *b = t == 0 ? row_bounds : col_bounds;
+		P->bounds[sd] = malloc(sizeof(int64_t) * (size_t)(nranks + 1));
+		if (!P->bounds[sd]) {
+			rc = blz_fail(BLZ_ENOMEM, "blz_prepare_rank: out of memory");
+			break;
+		}
+		memcpy(P->bounds[sd], b, sizeof(int64_t) * (size_t)(nranks + 1));
+		int64_t mx = 0;
+		for (int g = 0; g < nranks; g++)
+			if (b[g + 1] - b[g] > mx)
+				mx = b[g + 1] - b[g];
+		P->stride[sd] = (mx + chunks - 1) / chunks * chunks;
+		P->full_first[t] = b[rank];
+		blz_coo part = t == 0 ? *row_part : *col_part;
+		part.nrows = nrows;
+		part.ncols = ncols;
+		rc = csr_from_coo_window(&part, t, 1, b[rank], b[rank + 1] - b[rank], &P->full[t]);
+	}
+	if (rc != BLZ_OK) {
+		blz_prepared_free(P);
+		return rc;
+	}
+	*out = P;
+	return BLZ_OK;
+}
+
 /* rank `rank`'s rows of M (t = 0) or M^T (t = 1), columns rewritten to positions in the gathered operand */
 int blz_prepared_slab(const blz_prepared *P, int rank, int t, blz_csr *slab)
 {
 	if (!P || !slab || rank < 0 || rank >= P->nranks || t < 0 || t > 1)
 		return blz_fail(BLZ_EINVAL, "blz_prepared_slab: bad argument");
 	const int rs = t == 0 ? (P->right ? 1 : 0) : (P->right ? 0 : 1), cs = 1 - rs;
-	int rc = blz_csr_slab(&P->full[t], P->bounds[rs][rank], P->bounds[rs][rank + 1], slab);
+	if (P->only_rank >= 0 && rank != P->only_rank)
+		return blz_fail(BLZ_EINVAL, "blz_prepared_slab: this object holds rank %d's rows only", P->only_rank);
+	const int64_t off = P->only_rank >= 0 ? P->full_first[t] : 0;
+	int rc = blz_csr_slab(&P->full[t], P->bounds[rs][rank] - off, P->bounds[rs][rank + 1] - off, slab);
 	if (rc == BLZ_OK && P->nranks > 1) {
 		blz_remap_columns(slab, P->bounds[cs], P->nranks, P->stride[cs] / P->chunks, P->chunks);
 		slab->cols = P->stride[cs] * P->nranks;
@@ -1298,10 +1503,13 @@ int blz_prepared_slab_short(const blz_prepared *P, int rank, int t, blz_csr *out
 	memset(out, 0, sizeof *out);
 	const int rs = t == 0 ? (P->right ? 1 : 0) : (P->right ? 0 : 1), cs = 1 - rs;
 	const blz_csr *O = &P->full[1 - t];		/* rows on side cs, columns on side rs */
-	const int64_t b0 = P->bounds[cs][rank], b1 = P->bounds[cs][rank + 1];
+	if (P->only_rank >= 0 && rank != P->only_rank)
+		return blz_fail(BLZ_EINVAL, "blz_prepared_slab_short: this object holds rank %d's rows only", P->only_rank);
+	const int64_t off = P->only_rank >= 0 ? P->full_first[1 - t] : 0;	/* O's row q is global row off + q */
+	const int64_t b0 = P->bounds[cs][rank] - off, b1 = P->bounds[cs][rank + 1] - off;
 	const uint32_t k0 = O->row_ptr[b0], k1 = O->row_ptr[b1];
 	const int64_t nnz = (int64_t)k1 - k0, rows = (int64_t)P->nranks * P->stride[rs];
-	if (rows >= (int64_t)UINT32_MAX)
+	if (rows > (int64_t)INT32_MAX)		/* padded output positions are kept in int32 (pos[] below) */
 		return blz_fail(BLZ_EINVAL, "blz_prepared_slab_short: too many rows");
 	out->rows = rows;
 	out->cols = b1 - b0;
@@ -1382,6 +1590,8 @@ int blz_prepared_save(const blz_prepared *P, const char *path, uint64_t key)
 {
 	if (!P || !path)
 		return blz_fail(BLZ_EINVAL, "blz_prepared_save: bad argument");
+	if (P->only_rank >= 0)
+		return blz_fail(BLZ_EINVAL, "blz_prepared_save: a one-rank object (blz_prepare_rank) is not a cache of the matrix");
 	prep_header h;
 	memset(&h, 0, sizeof h);
 	memcpy(h.magic, PREP_MAGIC, 8);
@@ -1483,6 +1693,7 @@ int blz_prepared_load(const char *path, uint64_t key, blz_prepared **out)
 	}
 	P->map = m;
 	P->map_len = (size_t)st.st_size;
+	P->only_rank = -1;
 	P->nrows = h.nrows;
 	P->ncols = h.ncols;
 	P->nnz = h.nnz;
@@ -1504,6 +1715,69 @@ int blz_prepared_load(const char *path, uint64_t key, blz_prepared **out)
 		P->full[q].row_ptr = (uint32_t *)(m + h.off_rp[q]);
 		P->full[q].col_idx = (int32_t *)(m + h.off_ci[q]);
 		P->full[q].val = h.has_val[q] ? (uint32_t *)(m + h.off_va[q]) : NULL;
+	}
+	/* The header is input like any other (a truncated, stale or foreign FILENAME.<key>.blzcache next to the matrix): every
+	 * array must lie inside the file, and what the set-up indexes with -- row pointers, bounds, permutations, column
+	 * indices -- must be in range, or the caller prepares afresh (BLZ_EFORMAT).  ADVICE round 2. */
+	const char *why = NULL;
+	const uint64_t len = (uint64_t)st.st_size;
+#define INSIDE(off, bytes) ((off) >= sizeof(prep_header) && (off) <= len && (uint64_t)(bytes) <= len - (off) && ((off) & 7u) == 0)
+	if (h.nrows < 0 || h.ncols < 0 || h.nnz < 0 || h.nrows > INT32_MAX || h.ncols > INT32_MAX || h.nnz >= (int64_t)UINT32_MAX ||
+	    h.chunks < 1 || h.nranks > 65536)
+		why = "dimensions";
+	for (int q = 0; q < 2 && !why; q++) {
+		const int64_t rows = q == 0 ? h.nrows : h.ncols, cols = q == 0 ? h.ncols : h.nrows;
+		if ((h.has_perm && !INSIDE(h.off_perm[q], 4 * (uint64_t)rows)) || !INSIDE(h.off_bounds[q], 8 * (uint64_t)(h.nranks + 1)) ||
+		    !INSIDE(h.off_rp[q], 4 * (uint64_t)(rows + 1)) || !INSIDE(h.off_ci[q], 4 * (uint64_t)h.nnz) ||
+		    (h.has_val[q] && !INSIDE(h.off_va[q], 4 * (uint64_t)h.nnz))) {
+			why = "an array lies outside the file";
+			break;
+		}
+		const uint32_t *rp = P->full[q].row_ptr;
+		int64_t bad = rp[0] != 0 || rp[rows] != (uint32_t)h.nnz;
+#pragma omp parallel for schedule(static) reduction(+ : bad) if (rows > 200000)
+		for (int64_t r = 0; r < rows; r++)
+			bad += rp[r] > rp[r + 1];
+		const int32_t *ci = P->full[q].col_idx;
+#pragma omp parallel for schedule(static) reduction(+ : bad) if (h.nnz > 200000)
+		for (int64_t k = 0; k < h.nnz; k++)
+			bad += ci[k] < 0 || ci[k] >= cols;
+		if (bad) {
+			why = "row pointers or column indices out of range";
+			break;
+		}
+		if (h.has_perm) {
+			const int32_t *pm = P->perm[q];
+			int64_t oob = 0;
+#pragma omp parallel for schedule(static) reduction(+ : oob) if (rows > 200000)
+			for (int64_t r = 0; r < rows; r++)
+				oob += pm[r] < 0 || pm[r] >= rows;
+			if (oob) {
+				why = "permutation out of range";
+				break;
+			}
+		}
+	}
+	for (int sd = 0; sd < 2 && !why; sd++) {
+		/* side 0 = rows of v: rows of M for a left kernel, columns for a right one */
+		const int64_t dim = (sd == 0) == (h.right == 0) ? h.nrows : h.ncols;
+		const int64_t *b = P->bounds[sd];
+		int64_t mx = 0;
+		if (b[0] != 0 || b[h.nranks] != dim)
+			why = "partition bounds";
+		for (int g = 0; g < h.nranks && !why; g++) {
+			if (b[g] > b[g + 1])
+				why = "partition bounds";
+			else if (b[g + 1] - b[g] > mx)
+				mx = b[g + 1] - b[g];
+		}
+		if (!why && (h.stride[sd] < mx || h.stride[sd] % h.chunks != 0 || h.stride[sd] > mx + h.chunks))
+			why = "slab stride";
+	}
+#undef INSIDE
+	if (why) {
+		blz_prepared_free(P);
+		return blz_fail(BLZ_EFORMAT, "%s: damaged cache (%s)", path, why);
 	}
 	*out = P;
 	return BLZ_OK;

@@ -118,6 +118,17 @@ class Matrix:
         return Matrix._take(M)
 
     @staticmethod
+    def synth_part(nrows, ncols, nnz, seed, prime, rows=None, cols=None, pattern=False):
+        """the entries of synth(...)'s matrix in rows [rows[0], rows[1]) and columns [cols[0], cols[1]), global indices,
+        made without the rest of the matrix (blz_synth_coo_part)"""
+        r0, r1 = rows if rows is not None else (0, nrows)
+        c0, c1 = cols if cols is not None else (0, ncols)
+        M = Coo()
+        check(lib().blz_synth_coo_part(C.c_int64(nrows), C.c_int64(ncols), C.c_int64(nnz), C.c_uint64(seed), C.c_int(int(pattern)),
+                                       C.c_uint64(prime), C.c_int64(r0), C.c_int64(r1), C.c_int64(c0), C.c_int64(c1), C.byref(M)))
+        return Matrix._take(M)
+
+    @staticmethod
     def synth_structured(nrows, ncols, nnz, seed, prime, pattern=False, hot_pct=40, band_pct=30, band=4096):
         """Heavy-tailed column degrees + banded supports (blz_synth_structured): the extra, non-headline workload."""
         M = Coo()
@@ -178,6 +189,18 @@ class Prepared:
         h = C.c_void_p()
         check(lib().blz_prepare(C.byref(M.c), C.c_int(int(right)), C.c_int(nranks), C.c_int(chunks), C.c_int(reorder),
                                 C.c_int(rows_per_line), C.c_int64(hot_cap), C.c_double(min_share), C.byref(h)))
+        return Prepared(h)
+
+    @staticmethod
+    def prepare_rank(row_part, col_part, nrows, ncols, nnz_total, right, rank, nranks, row_bounds, col_bounds, chunks=1):
+        """one rank's prepared matrix from its own rows / columns of M alone (blz_prepare_rank)"""
+        rb = np.ascontiguousarray(row_bounds, dtype=np.int64)
+        cb = np.ascontiguousarray(col_bounds, dtype=np.int64)
+        assert len(rb) == nranks + 1 and len(cb) == nranks + 1
+        h = C.c_void_p()
+        check(lib().blz_prepare_rank(C.byref(row_part.c), C.byref(col_part.c), C.c_int64(nrows), C.c_int64(ncols),
+                                     C.c_int64(nnz_total), C.c_int(int(right)), C.c_int(rank), C.c_int(nranks), C.c_int(chunks),
+                                     rb.ctypes.data_as(C.POINTER(C.c_int64)), cb.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(h)))
         return Prepared(h)
 
     @staticmethod
@@ -378,6 +401,15 @@ class Context:
         kind = C.c_int(0)
         check(lib().blz_locality(self.h, loc, C.byref(kind)))
         return (float(loc[0]), float(loc[1])), int(kind.value)
+
+    def comm_info(self):
+        """(ranks, rank) as the RCCL communicator reports them; (-1, -1) without one"""
+        a, b = C.c_int(-1), C.c_int(-1)
+        check(lib().blz_comm_info(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def exchange_pieces(self, transpose):
+        return int(lib().blz_exchange_pieces(self.h, C.c_int(1 if transpose else 0)))
 
     def short_side(self, transpose):
         return bool(lib().blz_short_side(self.h, C.c_int(int(transpose))) == 1)

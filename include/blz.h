@@ -84,6 +84,12 @@ int blz_mm_save_coo(const char *path, const blz_coo *M);
  * {1,1,1,2,3,-1,-2} (pattern=0, canonicalised like the loader does) or all 1 (pattern=1). */
 int blz_synth_coo(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int pattern,
 		  uint64_t prime, blz_coo *out);
+/* The entries of that same matrix in rows [r0, r1) and columns [c0, c1), global indices, without making the rest
+ * (every row is seeded by itself): a rank's own rows (c0 = 0, c1 = ncols) or own columns (r0 = 0, r1 = nrows) of a
+ * matrix too large to hold whole -- config 5's 2e9 entries.  What the reference's MPI loader does with
+ * the file (mpi/lanczos_modp.c:1841-1845). */
+int blz_synth_coo_part(int64_t nrows, int64_t ncols, int64_t nnz, uint64_t seed, int pattern, uint64_t prime,
+		       int64_t r0, int64_t r1, int64_t c0, int64_t c1, blz_coo *out);
 
 /* A synthetic matrix WITH structure (never the headline workload): hot_pct % of a row's entries are drawn with
  * probability ~ 1/(c + 16) (heavy-tailed column degrees, dense columns first, as in a sieve relation matrix),
@@ -141,6 +147,14 @@ void blz_csr_sort_rows(blz_csr *A);
 typedef struct blz_prepared blz_prepared;
 int blz_prepare(const blz_coo *M, int right, int nranks, int chunks, int reorder, int rows_per_line, int64_t hot_cap,
 		double min_share, blz_prepared **out);
+/* One rank's prepared matrix from that rank's share alone: row_part / col_part = the entries of M in its rows / in its
+ * columns (global indices), the caller's partition (bounds: nranks + 1 ascending values from 0 to the dimension), the
+ * caller's numbering (no renumbering).  Only blz_set_matrix_prepared(ctx, P, rank) with that rank accepts it; it cannot
+ * be saved.  No process holds the whole matrix -- the reference's MPI variant works that way too
+ * (mpi/lanczos_modp.c:1841-1900). */
+int blz_prepare_rank(const blz_coo *row_part, const blz_coo *col_part, int64_t nrows, int64_t ncols, int64_t nnz_total,
+		     int right, int rank, int nranks, int chunks, const int64_t *row_bounds, const int64_t *col_bounds,
+		     blz_prepared **out);
 int blz_prepared_save(const blz_prepared *P, const char *path, uint64_t key);
 int blz_prepared_load(const char *path, uint64_t key, blz_prepared **out);
 void blz_prepared_free(blz_prepared *P);
@@ -343,6 +357,13 @@ int blz_set_exchange_mode(blz_ctx *ctx, int external);
  * >= 2 MB per slab, or BLZ_AG_CHUNKS). */
 int blz_comm_unique_id(void *id_out, size_t id_bytes);	/* needs id_bytes >= 128 */
 int blz_comm_init(blz_ctx *ctx, const void *id, size_t id_bytes, int rank, int nranks);
+/* What the communicator itself says (ncclCommCount / ncclCommUserRank), not what the caller passed in: -1, -1 when the
+ * context has none.  bench.py prints it so that an N > 1 line proves N ranks really met inside RCCL
+ * (the reference prints its MPI_Comm_size, mpi/lanczos_modp.c:1755-1757). */
+int blz_comm_info(const blz_ctx *ctx, int *nranks_seen, int *rank_seen);
+/* pieces the exchange of product `transpose`'s operand (and the product itself) is cut into; 0 in the short-side form,
+ * where nothing is gathered */
+int blz_exchange_pieces(const blz_ctx *ctx, int transpose);
 
 #ifdef __cplusplus
 }

@@ -226,6 +226,31 @@ class CsrPair:
         self.a = self.at = None
 
 
+class CsrOne:
+    """CSR of M (transpose=False) or of M^T alone, for one by-rows product (orc_spmv_csr_omp): y = A x with one output
+    row per loop iteration.  What the full-size slab tests compare a rank's product with."""
+
+    def __init__(self, M, transpose=False):
+        L = lib()
+        L.orc_csr_build.restype = C.c_void_p
+        L.orc_csr_free.argtypes = [C.c_void_p]
+        L.orc_csr_free.restype = None
+        self.rows = M.ncols if transpose else M.nrows
+        self.h = L.orc_csr_build(C.byref(M.c), C.c_int(1 if transpose else 0))
+        if not self.h:
+            raise MemoryError("orc_csr_build")
+
+    def spmv(self, x, n, prime, threads=0):
+        y = np.zeros(self.rows * n, dtype=np.uint64)
+        lib().orc_spmv_csr_omp(ptr(y), C.c_void_p(self.h), ptr(u64(x)), C.c_int(n), C.c_uint64(prime), C.c_int(threads))
+        return y
+
+    def close(self):
+        if self.h:
+            lib().orc_csr_free(C.c_void_p(self.h))
+        self.h = None
+
+
 def iteration_omp(M, n, prime, right, v, tmp, Av, pblk, threads=0):
     return lib().orc_iteration_omp(C.byref(M.c), C.c_int(n), C.c_uint64(prime), C.c_int(int(right)),
                                    ptr(v), ptr(tmp), ptr(Av), ptr(pblk), C.c_int(threads))

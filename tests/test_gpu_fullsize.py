@@ -93,6 +93,64 @@ def test_full_size_config(name):
     pair.close()
 
 
+@pytest.mark.parametrize("rank", [0, 7])
+def test_config5_one_ranks_share_at_full_size(rank):
+    """BASELINE config 5 at ITS OWN size, as one of its 8 GPUs sees it: the 50 M x 50 M / 2e9-entry all-ones matrix, n = 16,
+    p = 2^61-1, 8-way row partition.  The rank generates only its own 6.25 M rows and its own 6.25 M columns (2 x 2.5e8
+    entries, column indices up to 5e7 > 2^24, blz_synth_coo_part), prepares from that share alone (blz_prepare_rank) and
+    multiplies its slabs by the FULL 6.4 GB gathered operand (external-exchange mode: set_block hands over what the
+    all-gather would deliver).  One product per orientation against the oracle's by-rows kernel on those rows (the
+    reference's per-term semantics, sequential/lanczos_modp.c:277-286), plus linearity on one of them.  Ranks 0 and 7: the
+    first and the last slab of the gathered layout."""
+    w = WORKLOADS["synth5"]
+    p, n, nranks = w["prime"], w["n"], 8
+    R_, C_, nnz = w["rows"], w["cols"], w["nnz"]
+    shape = (R_, C_, nnz, w["seed"])
+    rb = [R_ * g // nranks for g in range(nranks + 1)]
+    cb = [C_ * g // nranks for g in range(nranks + 1)]
+    threads = min(16, os.cpu_count() or 1)
+    rows_part = blz.Matrix.synth_part(*shape, p, rows=(rb[rank], rb[rank + 1]), pattern=True)
+    cols_part = blz.Matrix.synth_part(*shape, p, cols=(cb[rank], cb[rank + 1]), pattern=True)
+    assert rows_part.nnz == (rb[rank + 1] - rb[rank]) * (nnz // R_) and rows_part.j.max() >= 1 << 24
+    assert abs(cols_part.nnz - nnz // nranks) < 1e-3 * nnz // nranks          # binomial column degrees
+    with blz.Context(p, n) as ctx:
+        with blz.Prepared.prepare_rank(rows_part, cols_part, R_, C_, nnz, False, rank, nranks, rb, cb) as P:
+            ctx.set_matrix_prepared(P, rank)
+        ctx.set_exchange_mode(True)
+        assert ctx.local_nnz(False) == rows_part.nnz and ctx.local_nnz(True) == cols_part.nnz
+        rng = np.random.default_rng(50 + rank)
+        # product 0: rows [rb] of M x (operand on the column side, TMP); product 1: rows [cb] of M^T x (operand V)
+        for transpose, src, dst, part, lo, hi in ((False, blz.TMP, blz.AV, rows_part, rb[rank], rb[rank + 1]),
+                                                  (True, blz.V, blz.TMP, cols_part, cb[rank], cb[rank + 1])):
+            rows_in = ctx.rows(src)
+            x = rng.integers(0, p, rows_in * n, dtype=np.uint64)              # the whole gathered operand: 6.4 GB
+            ctx.set_block(src, x)
+            ctx.spmv(transpose, src, dst)
+            y = ctx.get_block(dst)[lo * n:hi * n].copy()
+            # the same rows on the host, by rows, from the share alone (local row numbers)
+            if transpose:
+                Mo = orc.Matrix(R_, hi - lo, part.i, part.j - np.int32(lo), part.x)
+            else:
+                Mo = orc.Matrix(hi - lo, C_, part.i - np.int32(lo), part.j, part.x)
+            A = orc.CsrOne(Mo, transpose)
+            want = A.spmv(x, n, p, threads)
+            A.close()
+            del Mo
+            assert np.array_equal(y, want), (rank, transpose)
+            del want
+            if transpose == (rank == 7):
+                # linearity at this size: A (x + b) = A x + A b
+                b = rng.integers(0, p, rows_in * n, dtype=np.uint64)
+                ctx.set_block(src, b)
+                ctx.spmv(transpose, src, dst)
+                yb = ctx.get_block(dst)[lo * n:hi * n].copy()
+                ctx.set_block(src, addmod(x, b, p))
+                ctx.spmv(transpose, src, dst)
+                assert np.array_equal(ctx.get_block(dst)[lo * n:hi * n], addmod(y, yb, p))
+                del b, yb
+            del x, y
+
+
 def test_full_solve_finds_verified_kernel_vectors():
     """A whole solve at moderate scale (24 k iterations): 200 000 x 190 000, 2 M entries, n=8, p=2^61-1.  More rows than
     columns, so a left kernel exists; the block returned must be non-zero and annihilate M -- checked on the host

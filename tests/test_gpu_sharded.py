@@ -202,3 +202,31 @@ def test_short_side_exchange_through_rccl_on_one_rank(monkeypatch, shape, right)
         prof = c.profile_read()
         assert prof["reduce_scatter"]["launches"] == 14 and prof["allgather_v"]["launches"] == 0
         assert np.array_equal(c.get_block(blz.V), want["v"]) and np.array_equal(c.get_block(blz.P), want["p"])
+
+
+@pytest.mark.parametrize("shape,right", [((1500, 900), False), ((900, 1500), True)])
+def test_short_side_batch_past_the_stop_leaves_tmp_alone(monkeypatch, shape, right):
+    """A batch always runs past the stop (the CLI doubles its batch).  The reduce-scatter of a short-side product is
+    enqueued by the host whatever the flag says and, past the stop, sums STALE partial products -- with both products in
+    that form the stale buffer even belongs to the other product.  The collective therefore lands in a buffer of its own
+    and the stop-aware mod-p pass is what writes the slab: TMP after the batch must be the oracle's
+    M^T v, word for word residues, and blz_final_check must say what the reference's final_check says."""
+    monkeypatch.setenv("BLZ_FORCE_COMM", "1")
+    monkeypatch.setenv("BLZ_SHORT_SIDE", "1")
+    p, n = P61, 8
+    M = blz.Matrix.synth(shape[0], shape[1], 10 * max(shape), 0x53544F50, p)
+    Mo = orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+    full = orc.block_lanczos(Mo, n, p, right=right)
+    with blz.Context(p, n) as c:
+        c.comm_init(blz.comm_unique_id(), 0, 1)
+        c.set_matrix(M, right, 0, 1)
+        assert c.short_side(False) and c.short_side(True)
+        c.init_v()
+        done, stopped, _ = c.iterate(full["iterations"] + 37)
+        assert stopped and done == full["iterations"]
+        tmp = c.get_block(blz.TMP)
+        assert (tmp < p).all()
+        assert np.array_equal(tmp, full["tmp"]) and np.array_equal(c.get_block(blz.V), full["v"])
+        assert (c.get_small(blz.VTAV) < p).all() and (c.get_small(blz.VTAAV) < p).all()
+        v_nonzero, vtm_zero = c.final_check()
+        assert v_nonzero == bool(full["v"].any()) and vtm_zero == (not full["tmp"].any())

@@ -330,6 +330,101 @@ def test_short_side_form_of_a_product_sums_to_the_gathering_form(nranks, right):
                 assert not total[g * stride_out + G["rows"]:(g + 1) * stride_out].any()     # padding rows stay empty
 
 
+def _rows_sorted(S):
+    """a CSR slab as a list of per-row sorted (column, value) pairs (the order inside a row is not defined)"""
+    out = []
+    for r in range(S["rows"]):
+        a, b = S["row_ptr"][r], S["row_ptr"][r + 1]
+        out.append(sorted(zip(S["col_idx"][a:b].tolist(), S["val"][a:b].tolist())))
+    return out
+
+
+def test_part_generator_makes_the_same_entries_without_the_rest():
+    """blz_synth_coo_part: rows [r0, r1) x columns [c0, c1) of blz_synth_coo's matrix, global indices, rows ascending --
+    what a rank of a sharded solve generates for itself (config 5 is too large to hold whole)."""
+    p = (1 << 61) - 1
+    shape = (5000, 4000, 60003, 0x1234)
+    M = blz.Matrix.synth(*shape, p)
+    for rows, cols in (((1200, 2500), None), (None, (1000, 1777)), ((0, 5000), (0, 4000)), ((4999, 5000), (17, 3000)), ((7, 7), None)):
+        A = blz.Matrix.synth_part(*shape, p, rows=rows, cols=cols)
+        r0, r1 = rows or (0, 5000)
+        c0, c1 = cols or (0, 4000)
+        sel = (M.i >= r0) & (M.i < r1) & (M.j >= c0) & (M.j < c1)
+        assert np.array_equal(A.i, M.i[sel]) and np.array_equal(A.j, M.j[sel]) and np.array_equal(A.x, M.x[sel])
+    ones = blz.Matrix.synth_part(300, 200, 3000, 5, p, rows=(10, 20), pattern=True)
+    assert (ones.x == 1).all() and ones.nnz == 100
+    with pytest.raises(blz.BlzError):
+        blz.Matrix.synth_part(*shape, p, rows=(10, 5001))
+
+
+@pytest.mark.parametrize("nranks,chunks,right", [(2, 1, False), (3, 2, True), (8, 1, False)])
+def test_one_ranks_prepared_matrix_from_its_own_share_alone(tmp_path, nranks, chunks, right):
+    """blz_prepare_rank: a rank that only ever sees its own rows and its own columns of M must end up with the slabs
+    blz_prepare cuts out of the whole matrix (same partition, file numbering) -- gathering form and short-side form."""
+    p = (1 << 61) - 1
+    shape = (6000, 900, 30011, 0x52414E4B)
+    M = blz.Matrix.synth(*shape, p)
+    with blz.Prepared.prepare(M, right, nranks, chunks, reorder=0) as P:
+        _, _, _, b0, b1, stride = P.layout()
+        rb, cb = (b1, b0) if right else (b0, b1)          # side 0 = rows of v: rows of M for a left kernel
+        for g in range(nranks):
+            R = blz.Matrix.synth_part(*shape, p, rows=(rb[g], rb[g + 1]))
+            Cc = blz.Matrix.synth_part(*shape, p, cols=(cb[g], cb[g + 1]))
+            with blz.Prepared.prepare_rank(R, Cc, 6000, 900, M.nnz, right, g, nranks, rb, cb, chunks) as Q:
+                assert Q.layout()[3:] == (b0, b1, stride)
+                for t in (0, 1):
+                    want, got = P.slab(g, t), Q.slab(g, t)
+                    assert (got["rows"], got["cols"], got["nnz"]) == (want["rows"], want["cols"], want["nnz"])
+                    assert np.array_equal(got["row_ptr"], want["row_ptr"]) and _rows_sorted(got) == _rows_sorted(want)
+                    want, got = P.slab_short(g, t), Q.slab_short(g, t)
+                    assert np.array_equal(got["row_ptr"], want["row_ptr"]) and _rows_sorted(got) == _rows_sorted(want)
+                with pytest.raises(blz.BlzError):
+                    Q.slab((g + 1) % nranks, 0)           # it holds ONE rank's rows
+                with pytest.raises(blz.BlzError):
+                    Q.save(str(tmp_path / "no.blzcache"), 1)
+    with pytest.raises(blz.BlzError):                     # an entry outside the rank's rows is refused, not misfiled
+        blz.Prepared.prepare_rank(M, M, 6000, 900, M.nnz, right, 0, nranks, rb, cb, chunks)
+
+
+def test_a_damaged_cache_file_is_refused_not_trusted(tmp_path):
+    """blz_prepared_load must not index with what a truncated-then-padded, stale or hostile file says.
+    Every offset, row pointer, bound, permutation and column index is checked; the caller then prepares afresh."""
+    import struct
+    p = (1 << 61) - 1
+    M = blz.Matrix.load(os.path.join(GOLDEN, "rand300x200.mtx"), p)
+    path = str(tmp_path / "m.blzcache")
+    with blz.Prepared.prepare(M, False, 2, 1, reorder=1) as P:
+        P.save(path, 77)
+    good = open(path, "rb").read()
+    with blz.Prepared.load(path, 77) as L:
+        assert L.slab(0, 0)["nnz"] > 0
+    rng = np.random.default_rng(3)
+    refused = 0
+    # (a) the tail overwritten (column indices / values become garbage), (b) words of the header bumped, (c) random words
+    variants = [good[:len(good) - 2048] + bytes([0xFF]) * 2048]
+    for off in range(8, 8 * 40, 8):
+        b = bytearray(good)
+        struct.pack_into("<Q", b, off, struct.unpack_from("<Q", b, off)[0] + 4096)
+        variants.append(bytes(b))
+    for _ in range(40):
+        b = bytearray(good)
+        at = int(rng.integers(64, len(good) // 4 - 1)) * 4
+        struct.pack_into("<I", b, at, 0x7FFFFFF0)
+        variants.append(bytes(b))
+    for v in variants:
+        open(path, "wb").write(v)
+        try:
+            with blz.Prepared.load(path, 77) as L:          # accepted: then every slab must still be cut without a fault
+                for g in (0, 1):
+                    for t in (0, 1):
+                        S = L.slab(g, t)
+                        assert S["col_idx"].min(initial=0) >= 0 and S["col_idx"].max(initial=0) < max(S["cols"], 1)
+        except blz.BlzError as e:
+            assert e.code in (blz.EFORMAT, blz.EINVAL)
+            refused += 1
+    assert refused >= 30
+
+
 def test_bench_takes_the_real_file_when_the_directory_has_it(tmp_path, monkeypatch):
     """`$BLZ_MTX_DIR/<name>.mtx` replaces the seeded synthetic of the same workload (the SuiteSparse files
     are not on the box; a small file under the workload's name stands in here).  Host code only."""
