@@ -255,7 +255,7 @@ def measure(blz, torch, dist, ctx, info, w, steps, warmup, repeats):
                 loc_rows=(loc_v, loc_t),
                 t_spmv_ms=t_spmv_ms, alg_bytes=bytes1, achieved=bytes1 / (t_spmv_ms * 1e-3) / 1e9, nnz1=nnz1,
                 macs_per_step=macs_per_step, value=macs_per_step * steps / elapsed, word=word, rows_v=rows_v, rows_t=rows_t,
-                renumbering=dict(lines_per_entry=dict(M=loc[0], Mt=loc[1]), order=("smallest", "file", "mean")[kind]),
+                renumbering=dict(lines_per_entry=dict(M=loc[0], Mt=loc[1]), order=("smallest", "file", "mean", "sweeps")[kind]),
                 lds_panel={"spmv1": dict(zip(("rows", "share"), ctx.panel_rows(not right))),
                            "spmv2": dict(zip(("rows", "share"), ctx.panel_rows(right)))})
 

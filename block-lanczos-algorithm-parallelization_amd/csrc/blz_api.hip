@@ -270,6 +270,10 @@ extern "C" int blz_create(blz_ctx **out, int device, uint64_t prime, int n)
 		c->cfg.staged = !(ns && ns[0] == '1');
 		const char *su = getenv("BLZ_STAGE_U");		/* gathers in flight per lane of the staged SpMV: 4 / 8 (A/B); 0 = by plan */
 		c->cfg.stage_u = su ? atoi(su) : 0;
+		const char *npr = getenv("BLZ_NO_PAIR");
+		c->cfg.pair = !(npr && npr[0] == '1');
+		const char *sdy = getenv("BLZ_STAGE_DYN");
+		c->cfg.stage_dyn = sdy ? (sdy[0] == '1' ? 1 : 0) : -1;
 	}
 	{
 		const char *nsd = getenv("BLZ_NO_SIDE");
@@ -396,7 +400,7 @@ extern "C" void blz_destroy(blz_ctx *c)
 
 extern "C" int blz_word_bytes(const blz_ctx *c) { return c ? c->cfg.word : 0; }
 
-static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D, int64_t hot_rows = 0)
+static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D, int64_t hot_rows = 0, bool dot_slab = false)
 {
 	free_csr(D);
 	D.rows = H.rows;
@@ -496,7 +500,7 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D, int64_t hot_rows 
 		HIPCHK(hipMemcpy(D.heavy_multi, multi.data(), multi.size() * sizeof(HeavyRow), hipMemcpyHostToDevice));
 		HIPCHK(hipMalloc(&D.heavy_scratch, heavy.size() * 64 * 2 * sizeof(u64)));
 	}
-	spmv_plan_staged(c->cfg, H.row_ptr, D);
+	spmv_plan_staged(c->cfg, H.row_ptr, D, !dot_slab);
 	spmv_plan_panel(c->cfg, H.row_ptr, D, hot_rows);
 	return BLZ_OK;
 }
@@ -652,6 +656,8 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 		}
 		blz_csr slab;
 		memset(&slab, 0, sizeof slab);
+		/* product `right` is the second one of the iteration: its (last) launch carries the inner products where that form exists */
+		const bool dot_slab = t == right && c->fuse_dot && spmv_dot_supported(c->cfg);
 		const bool whole = nranks == 1;		/* one rank: the slab IS the prepared CSR, no copy */
 		if (whole)
 			slab = P->full[t];
@@ -660,7 +666,7 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 		if (K == 1) {
 			/* product t gathers block rows by the column index of its slab: columns of M for t = 0, rows of M for t = 1 */
 			const int64_t hot_t = c->cfg.panel ? P->hot[t == 0 ? 1 : 0] : 0;
-			rc = upload_csr(c, slab, c->csr[t][0], hot_t);
+			rc = upload_csr(c, slab, c->csr[t][0], hot_t, dot_slab);
 			const char *xe = getenv("BLZ_XCD_RANGES");	/* 0 / 1 force it off / on (A/B) */
 			/* (an operand of a few MB sits in every L2 anyway: nothing to separate) */
 			const bool big = (double)slab.cols * c->cfg.n * c->cfg.word > 8e6;
@@ -672,7 +678,7 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 			std::vector<blz_csr> piece((size_t)K);
 			rc = blz_csr_split_columns(&slab, width, K, piece.data());
 			for (int k = 0; k < K && rc == BLZ_OK; k++)
-				rc = upload_csr(c, piece[(size_t)k], c->csr[t][(size_t)k]);
+				rc = upload_csr(c, piece[(size_t)k], c->csr[t][(size_t)k], 0, dot_slab);
 			for (auto &pc : piece)
 				blz_csr_free(&pc);
 		}

@@ -40,7 +40,10 @@ struct DevCsr {
 	bool uneven = false;		/* row lengths vary a lot (std > mean/2): the SpMV wants more resident waves */
 	/* plan of the LDS-staged streaming kernel (k_spmv_staged), made at upload by spmv_plan_staged() */
 	bool st_ok = false;		/* false: the slab runs k_spmv / k_spmv_dot */
-	int st_rpg = 0;			/* rows per lane group per tile: a tile is (64/G) * st_rpg consecutive rows */
+	int st_rpg = 0;			/* lockstep form: rows per lane group per tile; a tile is st_tr = (64/G) * st_rpg consecutive rows */
+	int st_tr = 0;			/* rows per tile */
+	bool st_pair = false;		/* n = 16, 64-bit words: 8 lanes of two words per row (16-byte gathers), 8 rows per wavefront */
+	bool st_dyn = false;		/* the lane groups take the tile's rows from a shared counter (k_spmv_staged<..., DYN>) */
 	int st_capw = 0;		/* staging window per wavefront and buffer, entries */
 	int st_per_cu = 0;		/* resident workgroups per CU the grid is sized for */
 	int st_ns = 1;			/* streams staged: col_idx (+ val when it is a separate array) */
@@ -79,12 +82,14 @@ struct KernelCfg {
 	void *mfma_img;		/* device scratch for the coefficient digits in MFMA fragment order (ortho_mfma_image_bytes()) */
 	int panel;		/* 1: slabs whose operand has hot block rows run k_spmv_panel; BLZ_NO_PANEL=1 turns it off */
 	int staged;		/* 1: slabs with a plan run k_spmv_staged; BLZ_NO_STAGE=1 keeps the round-1 kernels (A/B) */
+	int pair;		/* 1: two words per lane in the staged SpMV at n = 16 (BLZ_NO_PAIR=1 turns it off) */
+	int stage_dyn;		/* -1: dynamic rows in the staged SpMV by plan; 0 / 1: forced off / on (BLZ_STAGE_DYN, read once) */
 	int stage_u;		/* 0: gathers in flight per lane of the staged SpMV chosen by the slab's plan; 4 / 8: forced (BLZ_STAGE_U, read once) */
 };
 
 /* fills the st_* fields of D from the host copy of its row pointers (D.rows, D.nnz, D.val, D.palette, D.kept_mean,
  * D.uneven must be set) */
-void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D);
+void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, bool allow_dyn);	/* allow_dyn: the slab never runs the fused (DOT) form */
 
 /* how many block rows the LDS panel of k_spmv_panel can hold for this context (0: the form is not available) */
 int64_t spmv_panel_capacity(const KernelCfg &c);

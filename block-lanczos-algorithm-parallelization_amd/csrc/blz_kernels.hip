@@ -892,7 +892,7 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 	heavy_fork(c, A, s);
 	if (A.panel_rows > 0 && c.panel)
 		return panel_dispatch<W, MERS, true>(c, A, X, Y, Vd, accum, partial, max_blocks, nblocks, ctl, s);
-	if (A.st_ok && c.staged)
+	if (A.st_ok && c.staged && !A.st_dyn)	/* (a slab planned for dynamic rows has tiles the lockstep form cannot walk) */
 		return staged_dispatch<W, MERS, true>(c, A, X, Y, Vd, accum, partial, max_blocks, nblocks, ctl, s);
 	const long long gpb = BLOCK / c.n;
 	long long blocks = (A.rows + gpb - 1) / gpb;
@@ -1010,13 +1010,69 @@ MODP_DEV void staged_accumulate(Acc &acc, u32 i, u32 i1, const u32 *sci, const u
 	}
 }
 
-template <typename W, int G, int MERS, bool DOT, int VALS, int U>
+/*
+ * DYN (round 3): the lane groups of a wavefront take the rows of a tile from a shared counter instead of in lockstep.
+ * With one row per group per step, every step lasts as long as its longest row, and a group that has finished issues
+ * no gathers meanwhile: on CSR(M^T) of the config-5 shape (Poisson row lengths around 40, four groups of 16 lanes) a
+ * step of four rows takes 6.3 batches of eight gathers on average where 5 would do, and the product ran 11 % slower
+ * than the one over the constant-length rows of CSR(M).  Here every group keeps its own position; at the top of a round
+ * the groups whose row is exhausted (one ballot) store it and take the next unassigned rows of the tile, the others go
+ * on gathering: a tile of R rows takes about (sum of the rows' batches) / groups rounds instead of the sum of the
+ * steps' maxima.  Rows stay whole and owned by one group -- same sums, same words, no cross-group reduction.
+ * TR is then any row count up to 64 (the row pointers of a tile are one register across the wavefront), chosen so that
+ * the tile's entries fill the staging window.
+ */
+/* The same batch with TWO adjacent words per lane (16-byte gathers: a 128-byte block row of n = 16 u64 words is 8 lanes,
+ * a wavefront holds 8 rows instead of 4 and issues half the vector-memory instructions per row).  tools/ubench5: the
+ * gather + output-row loop runs 5-9 % faster with 16 bytes per lane than with 8 (profiles/r03_ubench5_*.txt). */
+template <typename W, int VALS, int U>
+MODP_DEV void staged_accumulate2(Acc &a0, Acc &a1, u32 i, u32 i1, const u32 *sci, const u32 *sva, const u32 *spal,
+				 const W *__restrict__ X, int stride, int xw)
+{
+	typedef W W2 __attribute__((ext_vector_type(2)));
+	const u32 last = i1 - 1;
+	for (; i < i1; i += U) {
+		u32 c[U];
+		u32 a[U];
+		W2 x[U];
+#pragma unroll
+		for (int j = 0; j < U; j++) {
+			const u32 at = i + j < i1 ? i + j : last;
+			c[j] = sci[at];
+			if (VALS == V_ARRAY)
+				a[j] = sva[at];
+		}
+#pragma unroll
+		for (int j = 0; j < U; j++) {
+			x[j] = *(const W2 *)(X + (size_t)(VALS == V_PACKED ? (c[j] & 0xFFFFFFu) : c[j]) * stride + xw);
+			if (VALS == V_PACKED)
+				a[j] = spal[c[j] >> 24];
+		}
+#pragma unroll
+		for (int j = 0; j < U; j++) {
+			const bool live = i + j < i1;
+			if (VALS == V_ONES) {
+				acc_add(a0, live ? (u64)x[j].x : 0ull);
+				acc_add(a1, live ? (u64)x[j].y : 0ull);
+			} else {
+				acc_mac32(a0, live ? a[j] : 0u, x[j].x);
+				acc_mac32(a1, live ? a[j] : 0u, x[j].y);
+			}
+		}
+	}
+}
+
+/* WPL = words per lane: 1 (a group of G lanes owns a block row of up to G words) or 2 (the row is 2 G words, 16-byte
+ * gathers and stores; n = 2 G exactly, no fused inner products, lockstep rows) */
+template <typename W, int G, int MERS, bool DOT, int VALS, int U, bool DYN = false, int WPL = 1>
 __global__ void __launch_bounds__(BLOCK, (DOT && G >= 8) ? 4 : 1)	/* the fused form at n = 8 must keep 4 workgroups per CU (<= 128 VGPRs) */
 k_spmv_staged(const u32 *__restrict__ rp, const u32 *__restrict__ ci, const u32 *__restrict__ va,
 	      const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
-	      long long rows, int n, int rpg, int capw, int accum, u32 heavy, ModP m, u64 *__restrict__ partial,
+	      long long rows, int n, int tile_rows, int capw, int accum, u32 heavy, ModP m, u64 *__restrict__ partial,
 	      XcdTiles xt, const DevCtl *__restrict__ ctl)
 {
+	static_assert(!(DYN && DOT), "the dynamic form has no fused inner products (yet)");
+	static_assert(WPL == 1 || (WPL == 2 && !DOT && !DYN && sizeof(W) == 8), "two words per lane: plain lockstep form, 64-bit words");
 	if (ctl->stop)
 		return;
 	constexpr int GPW = 64 / G, NS = VALS == V_ARRAY ? 2 : 1, WAVES = BLOCK / 64, NT = DOT ? G : 1;
@@ -1030,7 +1086,7 @@ k_spmv_staged(const u32 *__restrict__ rp, const u32 *__restrict__ ci, const u32 
 	const int t = threadIdx.x, wl = t & 63, wave = t >> 6, lane = wl & (G - 1), grp = wl / G;
 	const int xl = lane < n ? lane : 0, gbase = wl - lane;
 	u32 *const mine = stage + (size_t)wave * 2 * NS * capw;
-	const int TR = GPW * rpg;
+	const int TR = tile_rows, rpg = TR / GPW;	/* lockstep form: TR = GPW * rows per group */
 	const int xcd = blockIdx.x & 7;
 	const long long nwv = xt.interleave ? (long long)gridDim.x * WAVES : (long long)(gridDim.x >> 3) * WAVES;
 	long long tile = xt.interleave ? (long long)blockIdx.x * WAVES + wave
@@ -1079,7 +1135,7 @@ k_spmv_staged(const u32 *__restrict__ rp, const u32 *__restrict__ ci, const u32 
 	 * operations retire in issue order, and the wait for the tile's stream then costs nothing -- with the store issued
 	 * last it exposed the full store latency once per tile (measured: +3..5 % on the GL7d19 shape). */
 	W *pend_at = nullptr;
-	u64 pend_y = 0;
+	u64 pend_y = 0, pend_y1 = 0;
 	int buf = 0;
 	for (; tile < tile_end; tile += nwv, buf ^= 1) {
 		/* everything this wavefront has issued so far has landed: this tile's stream and the next tile's row pointers */
@@ -1094,12 +1150,105 @@ k_spmv_staged(const u32 *__restrict__ rp, const u32 *__restrict__ ci, const u32 
 		const long long r0 = tile * TR;
 		const u32 K0 = (u32)__shfl((int)rv0, 0, 64) & ~3u;
 		const u32 *sci = mine + (size_t)buf * NS * capw, *sva = sci + capw;
+		if constexpr (DYN) {
+			constexpr unsigned long long LEAD = ~0ull / ((G < 64 ? (1ull << (G & 63)) : 0ull) - 1ull);	/* bit 0 of every group */
+			const unsigned long long below = (1ull << gbase) - 1ull;
+			const int tr = (int)(rows - r0 < (long long)TR ? rows - r0 : (long long)TR);
+			u32 gi = 0, ge = 0;		/* this group's position in its row, and the row's end (entries from K0) */
+			int grow = -1;			/* its row of the tile, or -1 */
+			int next = 0;			/* rows of the tile handed out so far (the same in every lane) */
+			Acc acc;
+			acc_zero(acc);
+			for (;;) {
+				const bool want = gi >= ge;
+				const unsigned long long wm = __ballot(want) & LEAD;
+				if (wm) {
+					/* the bounds of the row each asking group would get, fetched with every lane active (a lane that is
+					 * masked off supplies 0 to a cross-lane read) */
+					const int q = next + __popcll(wm & below), qq = q < tr ? q : 0;
+					const u32 k = (u32)__shfl((int)rv0, qq, 64);
+					const u32 en = (u32)__shfl((int)rv0, (qq + 1) & 63, 64);
+					const u32 e2 = qq + 1 < 64 ? en : re0;
+					if (want) {
+						if (grow >= 0 && lane < n) {
+							const long long r = r0 + grow;
+							if (accum)
+								acc_add(acc, Y[(size_t)r * n + lane]);
+							const u64 y = acc_reduce<MERS>(acc, m);
+							if (pend_at)
+								*pend_at = (W)pend_y;
+							pend_at = Y + (size_t)r * n + lane;
+							pend_y = y;
+						}
+						acc_zero(acc);
+						if (q < tr && e2 - k <= heavy) {	/* (rows above the outlier threshold belong to k_spmv_wave / _heavy) */
+							grow = q;
+							gi = k - K0;
+							ge = e2 - K0;
+						} else {
+							grow = -1;
+							gi = ge = 0;
+						}
+					}
+					next += __popcll(wm);
+				}
+				if (next >= tr && __ballot(grow >= 0) == 0)
+					break;
+				if (grow >= 0 && gi < ge) {
+					const u32 stop_at = gi + U < ge ? gi + U : ge;
+					if (ge <= (u32)capw)
+						staged_accumulate<W, VALS, U>(acc, gi, stop_at, sci, sva, spal_store, X, n, xl);
+					else		/* the row runs past the staged window: its entries come from global memory */
+						spmv_accumulate<W>(acc, K0 + gi, K0 + stop_at, (const int *)ci, VALS == V_ARRAY ? va : nullptr,
+								   VALS == V_PACKED ? spal_store : nullptr, X, n, xl);
+					gi = stop_at;
+				}
+			}
+		} else
 		for (int j = 0; j < rpg; j++) {
 			const int q = j * GPW + grp;
 			const long long r = r0 + q;
 			const u32 k = (u32)__shfl((int)rv0, q, 64);
 			const u32 enext = (u32)__shfl((int)rv0, (q + 1) & 63, 64);
 			const u32 e = q + 1 < 64 ? enext : re0;
+			if constexpr (WPL == 2) {
+				if (r < rows && e - k <= heavy) {
+					typedef W W2 __attribute__((ext_vector_type(2)));
+					Acc acc, acc1;
+					acc_zero(acc);
+					acc_zero(acc1);
+					if (e - K0 <= (u32)capw) {
+						staged_accumulate2<W, VALS, U>(acc, acc1, k - K0, e - K0, sci, sva, spal_store, X, n, 2 * lane);
+					} else {	/* the row runs past the staged window: its entries come from global memory */
+						for (u32 q = k; q < e; q++) {
+							const u32 cw = ci[q];
+							const W2 xv = *(const W2 *)(X + (size_t)(VALS == V_PACKED ? (cw & 0xFFFFFFu) : cw) * n + 2 * lane);
+							if (VALS == V_ONES) {
+								acc_add(acc, (u64)xv.x);
+								acc_add(acc1, (u64)xv.y);
+							} else {
+								const u32 av = VALS == V_PACKED ? spal_store[cw >> 24] : va[q];
+								acc_mac32(acc, av, xv.x);
+								acc_mac32(acc1, av, xv.y);
+							}
+						}
+					}
+					W *const yat = Y + (size_t)r * n + 2 * lane;
+					if (accum) {
+						const W2 old = *(const W2 *)yat;
+						acc_add(acc, (u64)old.x);
+						acc_add(acc1, (u64)old.y);
+					}
+					const u64 y0 = acc_reduce<MERS>(acc, m), y1 = acc_reduce<MERS>(acc1, m);
+					if (pend_at) {
+						const W2 pv = { (W)pend_y, (W)pend_y1 };
+						*(W2 *)pend_at = pv;
+					}
+					pend_at = yat;
+					pend_y = y0;
+					pend_y1 = y1;
+				}
+			} else
 			if (r < rows && e - k <= heavy) {
 				Acc acc;
 				acc_zero(acc);
@@ -1129,17 +1278,31 @@ k_spmv_staged(const u32 *__restrict__ rp, const u32 *__restrict__ ci, const u32 
 		rv1 = rv2;
 		re1 = re2;
 	}
-	if (pend_at)
-		*pend_at = (W)pend_y;
+	if (pend_at) {
+		if constexpr (WPL == 2) {
+			typedef W W2 __attribute__((ext_vector_type(2)));
+			const W2 pv = { (W)pend_y, (W)pend_y1 };
+			*(W2 *)pend_at = pv;
+		} else {
+			*pend_at = (W)pend_y;
+		}
+	}
 	if (DOT)
 		ds.finish(red, partial, m, (int)blockIdx.x);
 }
 
+/* two words per lane where the block row is 16 u64 words (see staged_accumulate2); BLZ_NO_PAIR=1 keeps one word per lane */
+static inline bool spmv_pair_lanes(const KernelCfg &c)
+{
+	return c.pair && c.n == 16 && c.word == 8;
+}
+
 /* Host side of the plan, made once per slab at upload (blz_api.hip): tile height, staging window, grid density and the
  * nnz-balanced tile ranges of the eight XCDs. */
-void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D)
+void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, bool allow_dyn)
 {
 	D.st_ok = false;
+	D.st_dyn = false;
 	if (D.rows <= 0 || D.nnz <= 0)
 		return;
 	int G = 1;
@@ -1147,6 +1310,9 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D)
 		G <<= 1;
 	if (spmv_split_log2(c, D.rows, D.nnz) != 0)	/* few long rows shared by adjacent groups: k_spmv */
 		return;
+	/* lanes per row: G, or 8 lanes of two words at n = 16 (8 rows per wavefront); the heuristics below go by the row width G */
+	const bool pair = spmv_pair_lanes(c) && !(c.stage_dyn == 1 && allow_dyn);
+	D.st_pair = pair;
 	{
 		/* Measured on MI355X (gpurun_out r2a..r2g, profiles/r02_staged_*): staging pays where the stream is a large
 		 * part of the row's work or rows span several lines of it -- relat9 shape, rows of 3 entries: 711 -> 668 us,
@@ -1161,7 +1327,7 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D)
 		if (!(e && e[0] == '1') && a >= 12.0 && a < 32.0)
 			return;
 	}
-	const int GPW = 64 / G, NS = (D.val && !D.palette) ? 2 : 1;
+	const int GPW = pair ? 8 : 64 / G, NS = (D.val && !D.palette) ? 2 : 1;
 	const double avg = D.kept_mean >= 0.0 ? D.kept_mean : (double)D.nnz / (double)D.rows;
 	/* Rows of a few entries (relat9 shape, 3.15 per row, profiles/r02_exp_staged_sweep_relat9.txt): a batch of 8 gathers
 	 * per lane is mostly switched-off slots, and 16 wavefronts per CU with the larger window beat 32 with the smaller one
@@ -1169,6 +1335,10 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D)
 	const bool few = avg < 6.0 && G < 16;
 	D.st_deep = !few;
 	int per_cu = c.spmv_blocks_per_cu > 0 ? c.spmv_blocks_per_cu : (((avg >= 12.0 || few) && G < 16) ? (D.uneven && !few ? 6 : 4) : 8);
+	/* two words per lane: 8 rows per wavefront keep the fabric busy with 16 wavefronts per CU and the larger window (config-5
+	 * quarter shape, per product: 11.85 / 11.17 ms at 8 workgroups per CU, 11.42 / 11.21 at 4, 14.08 / 11.99 at 6) */
+	if (pair && c.spmv_blocks_per_cu <= 0)
+		per_cu = 4;
 	/* LDS: 4 wavefronts x 2 buffers x capw entries x 4 B per block (x NS streams); 160 KB per CU */
 	int capw = (per_cu <= 4 ? 1024 : 512) / NS;
 	if (const char *e = getenv("BLZ_STAGE_CAPW"))
@@ -1187,7 +1357,27 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D)
 	}
 	if (rpg > 64 / GPW)
 		rpg = 64 / GPW;
-	const long long TR = (long long)GPW * rpg, nt = (D.rows + TR - 1) / TR;
+	long long TR = (long long)GPW * rpg;
+	/* Dynamic rows (k_spmv_staged<..., DYN>): where a wavefront holds few lane groups and the rows take several batches
+	 * each, so that a step of the lockstep form lasts as long as its longest row.  The tile is then as many rows as fill
+	 * ~85 % of the window on average (a tile that overflows it reads the overflowing rows from global memory).
+	 * BLZ_STAGE_DYN=0 / 1 forces it off / on wherever the kernel has the form (A/B). */
+	/* Measured on the config-5 quarter shape (profiles/r03_synth5q_dynamic_rows.txt): SLOWER than the lockstep form --
+	 * 12.67 / 12.43 ms against 12.45 / 11.68 per product -- although every lane group gathers in every round: the gathers
+	 * are bound by the fabric, not by idle groups, and the bookkeeping of a round costs issue slots.  Off unless asked for. */
+	bool dyn = false;
+	if (c.stage_dyn >= 0)
+		dyn = allow_dyn && c.stage_dyn == 1 && G >= 8 && G < 64;	/* (the launcher has the form for 8, 16 and 32 lanes per group) */
+	if (dyn) {
+		long long t = (long long)(0.85 * capw / (avg > 1.0 ? avg : 1.0));
+		if (const char *e = getenv("BLZ_STAGE_TR"))
+			if (atoi(e) >= 1)
+				t = atoi(e);
+		TR = t < GPW ? GPW : (t > 64 ? 64 : t);
+		D.st_dyn = true;
+	}
+	const long long nt = (D.rows + TR - 1) / TR;
+	D.st_tr = (int)TR;
 	D.st_rpg = rpg;
 	D.st_capw = capw;
 	D.st_per_cu = per_cu;
@@ -1227,17 +1417,32 @@ static void staged_launch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y,
 	bool deep = G >= 16 || (G == 8 && !DOT && A.st_deep);
 	if (c.stage_u > 0)
 		deep = c.stage_u >= 8;
-#define STAGED_GO(UU)                                                                                                   \
-	hipLaunchKernelGGL((k_spmv_staged<W, G, MERS, DOT, VALS, UU>), dim3((unsigned)blocks), dim3(BLOCK), lds, s, A.row_ptr, \
-			   (const u32 *)A.col_idx, A.val, A.palette, X, Y, Vd, (long long)A.rows, c.n, A.st_rpg, A.st_capw, accum, \
+#define STAGED_GO(UU, DD)                                                                                               \
+	hipLaunchKernelGGL((k_spmv_staged<W, G, MERS, DOT, VALS, UU, DD>), dim3((unsigned)blocks), dim3(BLOCK), lds, s, A.row_ptr, \
+			   (const u32 *)A.col_idx, A.val, A.palette, X, Y, Vd, (long long)A.rows, c.n, A.st_tr, A.st_capw, accum, \
 			   A.heavy_thr, c.m, partial, xt, ctl)
+	if constexpr (G == 16 && !DOT && sizeof(W) == 8) {
+		if (A.st_pair) {	/* 8 lanes of two words per row */
+			hipLaunchKernelGGL((k_spmv_staged<W, 8, MERS, false, VALS, 8, false, 2>), dim3((unsigned)blocks), dim3(BLOCK), lds, s,
+					   A.row_ptr, (const u32 *)A.col_idx, A.val, A.palette, X, Y, Vd, (long long)A.rows, c.n, A.st_tr, A.st_capw,
+					   accum, A.heavy_thr, c.m, partial, xt, ctl);
+			return;
+		}
+	}
 	if constexpr (G >= 8 && !DOT) {
-		if (deep)
-			STAGED_GO(8);
+		if (A.st_dyn) {
+			if constexpr (G < 64) {
+				if (deep)
+					STAGED_GO(8, true);
+				else
+					STAGED_GO(4, true);
+			}
+		} else if (deep)
+			STAGED_GO(8, false);
 		else
-			STAGED_GO(4);
+			STAGED_GO(4, false);
 	} else {
-		STAGED_GO(4);
+		STAGED_GO(4, false);
 	}
 #undef STAGED_GO
 }
@@ -1249,7 +1454,7 @@ static hipError_t staged_dispatch(const KernelCfg &c, const DevCsr &A, const W *
 	int G = 1;
 	while (G < c.n)
 		G <<= 1;
-	const long long TR = (long long)(64 / G) * A.st_rpg, nt = (A.rows + TR - 1) / TR;
+	const long long TR = A.st_tr, nt = (A.rows + TR - 1) / TR;
 	long long blocks = (nt + BLOCK / 64 - 1) / (BLOCK / 64);
 	long long cap = (long long)c.num_cu * A.st_per_cu;
 	long long hb = heavy_blocks(c, A, 1 << 30), cb = 0, mb = 0;
@@ -1706,11 +1911,34 @@ __device__ static u64 dev_invmod_mers61(u64 a, const ModP &m)
 	return mulmod<61>(sqn(x59, 2), x1, m);
 }
 
+/* ... and for p = 2^31 - 1: p - 2 = 2^31 - 3 is 29 ones, a zero and a one: 30 squarings and 8 products along
+ * 1, 2, 3, 6, 12, 24, 27, 29.  The extended Euclid costs ~20 steps with a 64-bit division each (a hundred instructions
+ * apiece on this chip): 5 of the 9.5 us of the semi-inverse kernel on the relat8 shape (round 3). */
+__device__ static u64 dev_invmod_mers31(u64 a, const ModP &m)
+{
+	auto sqn = [&](u64 x, int k) {
+		for (int i = 0; i < k; i++)
+			x = mulmod<31>(x, x, m);
+		return x;
+	};
+	const u64 x1 = a;
+	const u64 x2 = mulmod<31>(sqn(x1, 1), x1, m);
+	const u64 x3 = mulmod<31>(sqn(x2, 1), x1, m);
+	const u64 x6 = mulmod<31>(sqn(x3, 3), x3, m);
+	const u64 x12 = mulmod<31>(sqn(x6, 6), x6, m);
+	const u64 x24 = mulmod<31>(sqn(x12, 12), x12, m);
+	const u64 x27 = mulmod<31>(sqn(x24, 3), x3, m);
+	const u64 x29 = mulmod<31>(sqn(x27, 2), x2, m);
+	return mulmod<31>(sqn(x29, 2), x1, m);
+}
+
 template <int MERS>
 __device__ static u64 dev_invmod_any(u64 a, const ModP &m)
 {
 	if (MERS == 61)
 		return dev_invmod_mers61(a, m);
+	if (MERS == 31)
+		return dev_invmod_mers31(a, m);
 	return dev_invmod(a, m.p);
 }
 
@@ -2001,16 +2229,21 @@ __device__ static int ff_sweep_reg(u64 &a, u64 *w, u64 *s, int n, const ModP &m,
 		const u64 wy = w ? shfl64(*w, (j << LG) + k) : 0;
 		if (valid && i != j && mult != 0) {
 			const u64 neg = m.p - mult;
+			/* pv * a + neg * y is one 128-bit sum when two products fit between reductions (every prime below 2^61, and
+			 * 2^61 - 1 itself): one reduction per update instead of two */
+			const bool two = m.chunk >= 2;
 			Acc acc;
 			acc_zero(acc);
 			acc_mac64(acc, pv, a);
-			acc_set(acc, acc_reduce<MERS>(acc, m));
+			if (!two)
+				acc_set(acc, acc_reduce<MERS>(acc, m));
 			acc_mac64(acc, neg, y);
 			a = acc_reduce<MERS>(acc, m);
 			if (w) {
 				acc_zero(acc);
 				acc_mac64(acc, pv, *w);
-				acc_set(acc, acc_reduce<MERS>(acc, m));
+				if (!two)
+					acc_set(acc, acc_reduce<MERS>(acc, m));
 				acc_mac64(acc, neg, wy);
 				*w = acc_reduce<MERS>(acc, m);
 			}
@@ -2022,14 +2255,17 @@ __device__ static int ff_sweep_reg(u64 &a, u64 *w, u64 *s, int n, const ModP &m,
 	return found;
 }
 
-/* IMG: n = 8, p = 2^61 - 1: three more wavefronts wait at a barrier while wavefront 0 runs the sweep, then all four build
- * the coefficient image of the matrix-core block update from the coefficients wavefront 0 left in LDS. */
+/* IMG: n = 8, p = 2^61 - 1: fifteen more wavefronts wait at a barrier while wavefront 0 runs the sweep, then all sixteen
+ * build the coefficient image of the matrix-core block update from the coefficients wavefront 0 left in LDS.
+ * (Tried in round 3 and not kept: the partial rows of the inner products summed by this kernel itself, 1024 threads, where
+ * they are few -- relat8 shape, 256 rows of 32 words: 12.4 us against 4.4 + 8.5 for k_dot_finalize and this kernel apart,
+ * 57.4 against 56.8 us per iteration.) */
 template <int MERS, int LG, bool IMG>
-__global__ void __launch_bounds__(IMG ? 256 : 64)
+__global__ void __launch_bounds__(IMG ? 1024 : 64)
 k_semi_inverse_reg(const u64 *__restrict__ sums, u64 *__restrict__ small, DevCtl *__restrict__ ctl, int n, ModP m, int in_loop,
 		   unsigned char *__restrict__ img)
 {
-	constexpr int G = 1 << LG;
+	constexpr int G = 1 << LG, T = IMG ? 1024 : 64;
 	const int nn = n * n, lane = threadIdx.x, i = (lane & 63) >> LG, k = lane & (G - 1);
 	const bool valid = lane < 64 && i < n && k < n;
 	const int e = valid ? i * n + k : 0;
@@ -2117,7 +2353,7 @@ k_semi_inverse_reg(const u64 *__restrict__ sums, u64 *__restrict__ small, DevCtl
 	}
 	if constexpr (IMG) {
 		__syncthreads();
-		ortho_image_build<8>(coef, img, init_sh, lane, 256);
+		ortho_image_build<8>(coef, img, init_sh, lane, T);
 	}
 }
 
@@ -2142,8 +2378,8 @@ hipError_t launch_semi_inverse(const KernelCfg &c, const u64 *sums, u64 *small, 
 		else if (LG == 2) SEMI_REG(MM, 2);                                                                \
 		else SEMI_REG(MM, 3);                                                                             \
 	} while (0)
-		if (build_img)		/* n = 8, p = 2^61 - 1 (ortho_mfma_supported) */
-			hipLaunchKernelGGL((k_semi_inverse_reg<61, 3, true>), dim3(1), dim3(256), 0, s, sums, small, ctl, c.n, c.m, in_loop,
+		if (build_img)		/* n = 8, p = 2^61 - 1 (ortho_mfma_supported): 16 wavefronts, one 16-byte piece of the image each */
+			hipLaunchKernelGGL((k_semi_inverse_reg<61, 3, true>), dim3(1), dim3(1024), 0, s, sums, small, ctl, c.n, c.m, in_loop,
 					   img);
 		else if (c.mers == 61)
 			SEMI_REG_LG(61);

@@ -961,7 +961,8 @@ int blz_reorder_hot(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int6
  * a window.  The order with the fewest lines wins; locality[t] = lines / entries of product t under it (1 = every
  * entry its own line: nothing to reuse; the per-XCD row ranges of the SpMV are switched on below 0.85).
  */
-enum { ORD_SMALLEST = 0, ORD_IDENTITY = 1, ORD_BARYCENTRE = 2, ORD_KINDS = 3 };
+enum { ORD_SMALLEST = 0, ORD_IDENTITY = 1, ORD_BARYCENTRE = 2, ORD_SWEEPS = 3, ORD_KINDS = 4 };
+#define ORD_SWEEP_COUNT 4
 
 static int cmp_i32(const void *a, const void *b)
 {
@@ -1061,6 +1062,31 @@ static int finish_perm(const int32_t *key, int64_t count, int64_t nkeys, const u
 	return BLZ_OK;
 }
 
+/* one half-sweep of the barycentre heuristic: key[own] = mean over own's entries of pos[other] (entries whose other end is
+ * hot do not count), then positions by ascending key behind the hot items */
+static int barycentre_half(const blz_coo *M, int own_is_row, const int32_t *pos_other, int64_t n_own, int64_t n_other,
+			   unsigned char *const is_hot[2], int32_t *const list[2], const int64_t hot[2], double *sum, int32_t *cnt,
+			   int32_t *key, int32_t *perm_own)
+{
+	const int32_t *own = own_is_row ? M->i : M->j, *oth = own_is_row ? M->j : M->i;
+	const unsigned char *other_hot = is_hot[own_is_row ? 1 : 0];
+	memset(sum, 0, sizeof *sum * (size_t)n_own);
+	memset(cnt, 0, sizeof *cnt * (size_t)n_own);
+#pragma omp parallel for schedule(static) if (M->nnz > 200000)
+	for (int64_t k = 0; k < M->nnz; k++)
+		if (!other_hot[oth[k]]) {
+#pragma omp atomic
+			sum[own[k]] += (double)pos_other[oth[k]];
+#pragma omp atomic
+			cnt[own[k]]++;
+		}
+	for (int64_t r = 0; r < n_own; r++)
+		key[r] = cnt[r] ? (int32_t)(sum[r] / cnt[r]) : (int32_t)n_other;
+	const int sd = own_is_row ? 0 : 1;
+	return finish_perm(key, n_own, n_other, is_hot[sd], list[sd], hot[sd], perm_own);
+}
+
+/* kind ORD_SWEEPS starts from the column positions in col_perm (the best earlier candidate) and overwrites both */
 static int make_order(const blz_coo *M, int kind, unsigned char *const is_hot[2], int32_t *const list[2], const int64_t hot[2],
 		      int32_t *row_perm, int32_t *col_perm)
 {
@@ -1069,6 +1095,25 @@ static int make_order(const blz_coo *M, int kind, unsigned char *const is_hot[2]
 	double *sum = NULL;
 	int32_t *cnt = NULL;
 	int rc = key ? BLZ_OK : blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
+	if (rc == BLZ_OK && kind == ORD_SWEEPS) {
+		/* Iterated barycentre sweeps (the classic ordering heuristic for a bipartite graph: rows to the mean position of
+		 * their columns, columns to the mean position of their rows, a few times over): the stronger-than-one-pass
+		 * candidate SURVEY 8(f)4 and the round-2 verdict ask for.  It is scored like the others and kept only if it
+		 * leaves fewer lines to fetch. */
+		sum = malloc(sizeof *sum * (size_t)big);
+		cnt = malloc(sizeof *cnt * (size_t)big);
+		if (!sum || !cnt)
+			rc = blz_fail(BLZ_ENOMEM, "blz_reorder_auto: out of memory");
+		for (int sw = 0; sw < ORD_SWEEP_COUNT && rc == BLZ_OK; sw++) {
+			rc = barycentre_half(M, 1, col_perm, M->nrows, M->ncols, is_hot, list, hot, sum, cnt, key, row_perm);
+			if (rc == BLZ_OK)
+				rc = barycentre_half(M, 0, row_perm, M->ncols, M->nrows, is_hot, list, hot, sum, cnt, key, col_perm);
+		}
+		free(key);
+		free(sum);
+		free(cnt);
+		return rc;
+	}
 	if (rc == BLZ_OK && kind == ORD_BARYCENTRE) {
 		sum = malloc(sizeof *sum * (size_t)big);
 		cnt = malloc(sizeof *cnt * (size_t)big);
@@ -1189,10 +1234,25 @@ int blz_reorder_auto(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int
 	}
 	/* round 1's order and the file's own are always compared; the mean order only when the file's order already beats
 	 * round 1's by 10 % (there is structure to tidy) and the matrix is not huge (each candidate is two passes over it) */
-	double best = -1.0, score[ORD_KINDS] = { -1.0, -1.0, -1.0 };
+	double best = -1.0, score[ORD_KINDS] = { -1.0, -1.0, -1.0, -1.0 };
+	const char *verbose = getenv("BLZ_REORDER_VERBOSE");
+	const char *sw_env = getenv("BLZ_REORDER_SWEEPS");	/* 0: without the iterated barycentre sweeps (A/B) */
+	const int sweeps_off = sw_env && sw_env[0] == '0';
+	double best_frac = 1.0;		/* lines per entry of the best candidate so far, both products together */
 	for (int kind = 0; kind < ORD_KINDS && rc == BLZ_OK; kind++) {
+		/* the mean order and the sweeps only when the file's order already beats round 1's by 10 % (there is structure to
+		 * tidy) and the matrix is not huge (each candidate is several passes over it) */
 		if (kind == ORD_BARYCENTRE && !(score[ORD_IDENTITY] < 0.9 * score[ORD_SMALLEST] && M->nnz < 500000000))
 			continue;
+		/* the sweeps when an earlier candidate has found ANY locality (< 0.85 lines per entry over both products: the uniform
+		 * stand-ins sit at 0.89 under round 1's order and skip them) and the matrix is not huge.  Round 3, profiles/r03_reorder_sweeps.txt: a band
+		 * matrix whose rows and columns were scrambled goes from 0.72 / 0.45 (best earlier candidate) to 0.44 / 0.44 lines
+		 * per entry; the structured workload keeps its file order (0.55 / 0.23 against 0.80 / 0.95 for the sweeps: 30 % of
+		 * its entries are uniform and drag every mean to the middle). */
+		if (kind == ORD_SWEEPS && (sweeps_off || best_frac >= 0.85 || M->nnz >= 500000000))
+			continue;
+		if (kind == ORD_SWEEPS)		/* start from the best candidate so far */
+			memcpy(cand_c, col_perm, sizeof *cand_c * (size_t)N[1]);
 		if ((rc = make_order(M, kind, is_hot, list, hot, cand_r, cand_c)) != BLZ_OK)
 			break;
 		double ln[2], en[2];
@@ -1201,8 +1261,12 @@ int blz_reorder_auto(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int
 		score_product(N[1], M->j, cand_c, M->i, cand_r, M->nnz, line_shift, 4096, 32, is_hot[0], &ln[1], &en[1]);
 		const double tot = ln[0] + ln[1];
 		score[kind] = tot;
+		if (verbose && verbose[0] == '1')
+			fprintf(stderr, "blz_reorder_auto: order %d: %.3f / %.3f lines per entry (M x / M^T x)\n", kind,
+				en[0] > 0.0 ? ln[0] / en[0] : 1.0, en[1] > 0.0 ? ln[1] / en[1] : 1.0);
 		if (best < 0.0 || tot < best * 0.995) {	/* a later candidate must win by more than the sampling noise */
 			best = tot;
+			best_frac = en[0] + en[1] > 0.0 ? tot / (en[0] + en[1]) : 1.0;
 			memcpy(row_perm, cand_r, sizeof *cand_r * (size_t)N[0]);
 			memcpy(col_perm, cand_c, sizeof *cand_c * (size_t)N[1]);
 			locality[0] = en[0] > 0.0 ? ln[0] / en[0] : 1.0;

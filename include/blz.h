@@ -126,7 +126,7 @@ int blz_reorder_hot(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int6
  * orders -- rows by smallest column (blz_reorder), the file's own order, rows by the mean of their columns -- judged on a
  * sample of windows of 4096 consecutive rows of each product by the number of distinct 128-byte lines of the operand
  * they touch (rows_per_line block rows share a line).  locality[t] = lines per gathered entry of product t (0: M * x,
- * 1: M^T * x) under the chosen order; 1.0 means no reuse to be had.  *kind (may be NULL): 0 smallest, 1 file order,
+ * 1: M^T * x) under the chosen order; 1.0 means no reuse to be had.  *kind (may be NULL): 0 smallest, 1 file order, 3 iterated barycentre sweeps,
  * 2 mean. */
 int blz_reorder_auto(const blz_coo *M, int32_t *row_perm, int32_t *col_perm, int64_t hot[2], double min_share,
 		     double share[2], int rows_per_line, double locality[2], int *kind);

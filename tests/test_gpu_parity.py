@@ -388,6 +388,104 @@ def test_staged_matrix_stream_against_oracle(monkeypatch, n, p, kind, capw, rpg)
                 assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
 
 
+@pytest.mark.parametrize("capw,rpg", [(None, None), ("64", "1"), ("128", "3"), ("4096", "8")])
+@pytest.mark.parametrize("p,kind", [(P61, "ones"), (P61, "packed"), ((1 << 62) - 57, "array"), (2305843009213693907, "packed")])
+def test_two_words_per_lane_at_n16_against_oracle(monkeypatch, p, kind, capw, rpg):
+    """Round 3: at n = 16 (64-bit words) a block row is gathered by 8 lanes of two words (16 bytes per lane, 8 rows per
+    wavefront) instead of 16 lanes of one.  Same sums per word, so the same words as the oracle and as the one-word form
+    (BLZ_NO_PAIR=1): every value mode, windows that rows overflow, an outlier row, both orientations, whole iterations."""
+    monkeypatch.setenv("BLZ_STAGE_ALWAYS", "1")
+    if capw:
+        monkeypatch.setenv("BLZ_STAGE_CAPW", capw)
+        monkeypatch.setenv("BLZ_STAGE_RPG", rpg)
+    n = 16
+    rng = np.random.default_rng(len(kind) * 31 + p % 97)
+    nr, nc, nz = 8000, 7700, 160000
+    ii, jj = rng.integers(0, nr, nz), rng.integers(0, nc, nz)
+    ii[:3000] = 23
+    ii[3000:5000] = rng.integers(200, 230, 2000)
+    if kind == "ones":
+        xx = np.ones(nz, dtype=np.uint32)
+    elif kind == "packed":
+        xx = rng.choice(np.array([1, 2, 3, 2 ** 32 - 1, 2 ** 32 - 2], dtype=np.uint64), size=nz).astype(np.uint32)
+    else:
+        xx = rng.integers(1, 2 ** 32, size=nz, dtype=np.uint64).astype(np.uint32)
+    xx = (xx.astype(np.uint64) % p).astype(np.uint32)
+    M = blz.Matrix(nr, nc, ii, jj, xx)
+    Mo = as_orc(M)
+    for right in (False, True):
+        want = orc.block_lanczos(Mo, n, p, right=right, stop_after=3)
+        for flag in ("0", "1"):
+            monkeypatch.setenv("BLZ_NO_PAIR", flag)
+            with blz.Context(p, n) as ctx:
+                ctx.set_matrix(M, right)
+                for t, src, dst in ((right, blz.TMP, blz.AV), (not right, blz.V, blz.TMP)):
+                    x = (np.arange(ctx.rows(src) * n, dtype=np.uint64) * 2654435761 + 99) % p
+                    ctx.set_block(src, x)
+                    ctx.spmv(t, src, dst)
+                    assert np.array_equal(ctx.get_block(dst), orc.spmv(Mo, x, t, n, p)), (right, flag, t)
+                ctx.init_v()
+                ctx.iterate(3)
+                assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
+            if capw is None and kind in ("ones", "array"):
+                # products cut into three column pieces (the exchange pipeline's form): pieces 2 and 3 ADD to the rows piece 1 wrote
+                monkeypatch.setenv("BLZ_FORCE_COMM", "1")
+                monkeypatch.setenv("BLZ_AG_CHUNKS", "3")
+                with blz.Context(p, n) as ctx:
+                    ctx.comm_init(blz.comm_unique_id(), 0, 1)
+                    ctx.set_matrix(M, right, 0, 1)
+                    ctx.init_v()
+                    ctx.iterate(3)
+                    assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
+                monkeypatch.delenv("BLZ_FORCE_COMM")
+                monkeypatch.delenv("BLZ_AG_CHUNKS")
+
+
+@pytest.mark.parametrize("capw,tr", [(None, None), ("64", "5"), ("256", "64"), ("4096", "1")])
+@pytest.mark.parametrize("n,p,kind", [(16, P61, "ones"), (16, P61, "packed"), (8, P61, "packed"), (8, 2147483647, "array"),
+                                      (12, (1 << 62) - 57, "array"), (32, 1073741789, "ones")])
+def test_dynamic_rows_in_the_staged_stream_against_oracle(monkeypatch, n, p, kind, capw, tr):
+    """k_spmv_staged<..., DYN> (round 3): the lane groups of a wavefront take the rows of a tile from a shared counter
+    instead of one row each in lockstep.  Rows stay whole and owned by one group, so the words must be the oracle's: rows
+    of very different lengths (empty rows, one outlier row, a band of long rows), every value mode, tiles of 1 ... 64 rows,
+    windows that rows overflow (those read their entries from global memory), both orientations; and the same words with the
+    form switched off.  With n <= 8 the second product of an iteration keeps the lockstep form (it carries the inner
+    products), the first runs the dynamic one."""
+    monkeypatch.setenv("BLZ_STAGE_ALWAYS", "1")
+    if capw:
+        monkeypatch.setenv("BLZ_STAGE_CAPW", capw)
+        monkeypatch.setenv("BLZ_STAGE_TR", tr)
+    rng = np.random.default_rng(n * 77 + len(kind))
+    nr, nc, nz = 7000, 7300, 150000
+    ii, jj = rng.integers(0, nr, nz), rng.integers(0, nc, nz)
+    ii[:3000] = 17                                        # one outlier row
+    ii[3000:6000] = rng.integers(100, 130, 3000)          # a band of rows of ~100 entries
+    ii[(ii >= 2000) & (ii < 2100)] = 2100                 # a hundred empty rows in a row
+    if kind == "ones":
+        xx = np.ones(nz, dtype=np.uint32)
+    elif kind == "packed":
+        xx = rng.choice(np.array([1, 2, 3, 2 ** 32 - 1, 2 ** 32 - 2], dtype=np.uint64), size=nz).astype(np.uint32)
+    else:
+        xx = rng.integers(1, 2 ** 32, size=nz, dtype=np.uint64).astype(np.uint32)
+    xx = (xx.astype(np.uint64) % p).astype(np.uint32)
+    M = blz.Matrix(nr, nc, ii, jj, xx)
+    Mo = as_orc(M)
+    for right in (False, True):
+        want = orc.block_lanczos(Mo, n, p, right=right, stop_after=3)
+        for flag in ("1", "0"):
+            monkeypatch.setenv("BLZ_STAGE_DYN", flag)
+            with blz.Context(p, n) as ctx:
+                ctx.set_matrix(M, right)
+                for t, src, dst in ((right, blz.TMP, blz.AV), (not right, blz.V, blz.TMP)):
+                    x = (np.arange(ctx.rows(src) * n, dtype=np.uint64) * 2654435761 + 12345) % p
+                    ctx.set_block(src, x)
+                    ctx.spmv(t, src, dst)
+                    assert np.array_equal(ctx.get_block(dst), orc.spmv(Mo, x, t, n, p)), (right, flag, t)
+                ctx.init_v()
+                ctx.iterate(3)
+                assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
+
+
 @pytest.mark.parametrize("n,p,kind", [(8, P61, "packed"), (4, 2147483647, "packed"), (16, P61, "ones"), (2, (1 << 62) - 57, "array"),
                                       (1, 65537, "packed"), (32, 1073741789, "ones")])
 def test_panel_of_dense_block_rows_against_oracle(monkeypatch, n, p, kind):

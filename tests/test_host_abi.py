@@ -256,6 +256,31 @@ def test_renumbering_is_chosen_by_the_lines_it_leaves_to_fetch():
     assert np.array_equal(np.sort(rp_s), np.arange(60000)) and kind_s in (1, 2) and max(loc_s) < 0.5
 
 
+def test_iterated_sweeps_recover_a_hidden_band():
+    """Round 3 (a stronger ordering than the one-pass candidates): a band matrix whose rows and columns were
+    scrambled has no locality in its file order and little under rows-by-smallest-column; iterated barycentre sweeps, started
+    from the best earlier candidate and scored like the others, must be chosen and leave far fewer lines to fetch.  The same
+    matrix in its own banded order keeps it (the sweeps are scored, not trusted), and BLZ_REORDER_SWEEPS=0 takes them out."""
+    rng = np.random.default_rng(5)
+    R = C = 60000
+    per, band = 16, 600
+    i = np.repeat(np.arange(R), per)
+    j = (i + rng.integers(-band // 2, band // 2, size=R * per)) % C
+    x = np.ones(R * per, dtype=np.uint32)
+    pr, pc = rng.permutation(R), rng.permutation(C)
+    rp, cp, _, _, loc, kind = blz.reorder_auto(blz.Matrix(R, C, pr[i], pc[j], x), rows_per_line=2)
+    assert kind == 3 and max(loc) < 0.6
+    assert np.array_equal(np.sort(rp), np.arange(R)) and np.array_equal(np.sort(cp), np.arange(C))
+    os.environ["BLZ_REORDER_SWEEPS"] = "0"
+    try:
+        _, _, _, _, loc0, kind0 = blz.reorder_auto(blz.Matrix(R, C, pr[i], pc[j], x), rows_per_line=2)
+    finally:
+        del os.environ["BLZ_REORDER_SWEEPS"]
+    assert kind0 != 3 and sum(loc0) > 1.15 * sum(loc)
+    _, _, _, _, loc_b, kind_b = blz.reorder_auto(blz.Matrix(R, C, i, j, x), rows_per_line=2)
+    assert kind_b in (0, 1) and max(loc_b) < 0.1
+
+
 @pytest.mark.parametrize("nranks,chunks,right", [(1, 1, False), (2, 1, True), (3, 4, False)])
 def test_prepared_matrix_is_what_every_rank_used_to_build_and_survives_the_cache(tmp_path, nranks, chunks, right):
     """blz_prepare does the rank-independent set-up once; blz_prepared_slab cuts a rank's slabs out of it -- the same slabs
