@@ -52,8 +52,10 @@ WORKLOADS = {
     "synth5q": dict(desc="config-5-shape synthetic at 1/4 linear scale (all-ones pattern)", rows=12500000, cols=12500000,
                     nnz=500000000, prime=P61, n=16, right=False, seed=0x53594E35, pattern=True),
     # config 5 at FULL size on one GPU (fits: ~42 GB of the 288 GB HBM); minutes of host-side set-up
-    "synth5": dict(desc="config-5 synthetic (all-ones pattern), full size on ONE GPU", rows=50000000, cols=50000000,
-                   nnz=2000000000, prime=P61, n=16, right=False, seed=0x53594E35, pattern=True),
+    # (with N > 1 every rank generates and prepares ONLY its own rows and columns -- blz_synth_coo_part, blz_prepare_rank --
+    # so no process ever holds the 24 GB of triplets: `python bench.py --gpus 8 --workload synth5` is BASELINE config 5)
+    "synth5": dict(desc="config-5 synthetic (all-ones pattern), full size", rows=50000000, cols=50000000,
+                   nnz=2000000000, prime=P61, n=16, right=False, seed=0x53594E35, pattern=True, per_rank=True),
     # EXTRA workload, not a BASELINE config and never the headline: a matrix WITH structure (heavy-tailed column degrees,
     # banded supports -- the shape of a sieve relation matrix), for what the uniform stand-ins cannot show: the renumbering
     # chosen by line footprint, the per-XCD row ranges and the LDS panel of the SpMV
@@ -62,6 +64,8 @@ WORKLOADS = {
                 seed=0x4E465331, pattern=False, structured=dict(hot_pct=40, band_pct=30, band=4096)),
     "tiny": dict(desc="tiny synthetic (self-test)", rows=20000, cols=15000, nnz=200000, prime=P61,
                  n=8, right=False, seed=0x54494E59, pattern=False),
+    "tiny5": dict(desc="tiny config-5-like synthetic (self-test of the per-rank set-up)", rows=60000, cols=60000, nnz=1800000, prime=P61,
+                  n=16, right=False, seed=0x54494E35, pattern=True, per_rank=True),
 }
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 REPEATS = 5             # timed regions of K steps each; the median one is reported
@@ -353,7 +357,13 @@ def main():
     # shares it through a cache file that the other ranks map (one copy of the pages per node); every rank then uploads
     # its own slabs.  Round 1 generated, renumbered and built the whole matrix in every process.
     M, data, info = None, None, None
-    if rank == 0:
+    # every rank makes its own share; nobody holds the whole matrix (BLZ_BENCH_PER_RANK=1: also with one rank under a launcher,
+    # the way to run that code on a one-GPU box)
+    per_rank = bool(w.get("per_rank")) and (world > 1 or (os.environ.get("BLZ_BENCH_PER_RANK") == "1" and "RANK" in os.environ))
+    if per_rank:
+        data = "synthetic (every rank generates its own rows and columns of the same seeded matrix)"
+        info = dict(nrows=w["rows"], ncols=w["cols"], nnz=w["nnz"], pattern=bool(w["pattern"]), data=data)
+    elif rank == 0:
         M, data = make_matrix(blz, w, p)
         info = dict(nrows=M.nrows, ncols=M.ncols, nnz=M.nnz, pattern=bool((M.x == 1).all()), data=data)
     if dist is not None:
@@ -372,7 +382,25 @@ def main():
     # BLZ_BENCH_SHARE=1 takes the multi-rank set-up path (prepare, cache file, map, upload) with one rank as well, and makes
     # rank 0 map the file like the others: the way to run that code on a one-GPU box (tests/test_gpu_cli.py)
     share_test = dist is not None and os.environ.get("BLZ_BENCH_SHARE") == "1"
-    if world == 1 and not share_test:
+    if per_rank:
+        mine = None
+        try:
+            R_, C_, nnz_ = w["rows"], w["cols"], w["nnz"]
+            rb = [R_ * g // world for g in range(world + 1)]        # equal rows = equal entries (every row has nnz / R of them)
+            cb = [C_ * g // world for g in range(world + 1)]
+            rows_part = blz.Matrix.synth_part(R_, C_, nnz_, w["seed"], p, rows=(rb[rank], rb[rank + 1]), pattern=w["pattern"])
+            cols_part = blz.Matrix.synth_part(R_, C_, nnz_, w["seed"], p, cols=(cb[rank], cb[rank + 1]), pattern=w["pattern"])
+            K = ctx.exchange_pieces_for(R_, C_, nnz_, world)
+            with blz.Prepared.prepare_rank(rows_part, cols_part, R_, C_, nnz_, right, rank, world, rb, cb, chunks=K) as P:
+                ctx.set_matrix_prepared(P, rank)
+            del rows_part, cols_part
+        except Exception as exc:
+            mine = repr(exc)
+        errs = [None] * world
+        dist.all_gather_object(errs, mine)
+        if any(errs):
+            leave(1, f"per-rank set-up failed: {[e for e in errs if e]}")
+    elif world == 1 and not share_test:
         ctx.set_matrix(M, right, 0, 1)
     else:
         import shutil
@@ -625,12 +653,26 @@ def main():
     verdict = 1
     if dist is not None:
         iters_done = ctx.iterations
-        mine = int(ctx.get_block(blz.V).sum(dtype=np.uint64))          # rows of other ranks are left at zero
+        mine = 0 if per_rank else int(ctx.get_block(blz.V).sum(dtype=np.uint64))          # rows of other ranks are left at zero
         tot = torch.tensor([mine & 0x7FFFFFFF, (mine >> 31) & 0x7FFFFFFF, mine >> 62], dtype=torch.int64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         its_t = torch.tensor([iters_done], dtype=torch.int64)
         dist.all_reduce(its_t, op=dist.ReduceOp.MAX)
-        if rank == 0:
+        if rank == 0 and per_rank:
+            # nobody holds the whole matrix: no single-GPU solve to compare with.  What every rank CAN check after its iterations
+            # are the reference's own in-loop invariants on the (replicated) n x n operands: vtAv, vtAAv, winv symmetric and
+            # winv * vtAv * D = D (correctness_tests, sequential/lanczos_modp.c:532-557) -- they only hold if the all-gathers,
+            # the all-reduce and every rank's products were right.
+            A_, B_, Wi, d_ = (ctx.get_small(k_).astype(object) for k_ in (blz.VTAV, blz.VTAAV, blz.WINV, blz.D))
+            A_, B_, Wi = A_.reshape(n, n), B_.reshape(n, n), Wi.reshape(n, n)
+            D_ = np.diag(d_)
+            ok = bool((A_ == A_.T).all() and (B_ == B_.T).all() and (Wi == Wi.T).all() and ((Wi.dot(A_.dot(D_))) % p == D_).all()
+                      and A_.any())
+            out["sharded_equals_single_gpu"] = {"equal": None, "iterations": iters_done, "invariants_hold": ok,
+                                                "check": "the whole matrix is never made: the reference's in-loop invariants "
+                                                         "(symmetry, winv*vtAv*D = D) on the replicated n x n operands instead"}
+            verdict = 1 if ok else 0
+        elif rank == 0:
             total = (int(tot[0]) + (int(tot[1]) << 31) + (int(tot[2]) << 62)) & ((1 << 64) - 1)
             saved = {k_: os.environ.pop(k_) for k_ in ("BLZ_FORCE_COMM",) if k_ in os.environ}
             one = blz.Context(p, n, device=local_rank)

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <atomic>
 
 #include "blz_internal.h"
 #include "blz_kernels.h"
@@ -147,7 +148,7 @@ struct blz_ctx {
 	void *snap_host[2] = { nullptr, nullptr };
 	void *snap_dev[2] = { nullptr, nullptr };	/* device-side copy the D2H reads from while the loop goes on (nullptr: no room) */
 	size_t snap_bytes = 0;
-	bool snap_pending = false;
+	std::atomic<bool> snap_pending{ false };	/* set by the owner (begin), cleared by whoever collects (wait: possibly another thread) */
 	int64_t snap_iterations = 0;
 	/* short-side exchange (tall / wide matrices on several ranks): product t multiplies the transpose of this rank's rows
 	 * of the other orientation by its OWN slab and reduce-scatters the full-length partial products */
@@ -1461,7 +1462,7 @@ extern "C" int blz_profile_read(blz_ctx *c, double *ms_sum, int64_t *launches)
 extern "C" int blz_snapshot_begin(blz_ctx *c)
 {
 	NEED_MATRIX(c);
-	if (c->snap_pending)
+	if (c->snap_pending.load(std::memory_order_acquire))
 		return blz_fail(BLZ_EINVAL, "blz_snapshot_begin: the previous snapshot has not been collected (blz_snapshot_wait)");
 	if (!c->cstream) {
 		HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
@@ -1502,15 +1503,15 @@ extern "C" int blz_snapshot_begin(blz_ctx *c)
 	if (!staged)
 		HIPCHK(hipStreamWaitEvent(c->stream, c->ev_snap_done, 0));	/* later kernels overwrite v and p in place */
 	c->snap_iterations = c->host_ctl.iterations;
-	c->snap_pending = true;
+	c->snap_pending.store(true, std::memory_order_release);
 	return BLZ_OK;
 }
 
 extern "C" int blz_snapshot_wait(blz_ctx *c, uint64_t *v, uint64_t *p, int64_t *iterations)
 {
-	if (!c || !v || !p)
+	if (!c || (!v) != (!p))
 		return blz_fail(BLZ_EINVAL, "blz_snapshot_wait: NULL argument");
-	if (!c->snap_pending)
+	if (!c->snap_pending.load(std::memory_order_acquire))
 		return blz_fail(BLZ_EINVAL, "blz_snapshot_wait: no snapshot in flight");
 	HIPCHK(hipSetDevice(c->device));
 	/* polled, not hipEventSynchronize: this runs on the writer's thread while the owner keeps launching, and a blocking
@@ -1526,7 +1527,7 @@ extern "C" int blz_snapshot_wait(blz_ctx *c, uint64_t *v, uint64_t *p, int64_t *
 	}
 	const int un = c->un, np = c->cfg.n, sd = 0;
 	uint64_t *dst[2] = { v, p };
-	for (int b = 0; b < 2; b++) {
+	for (int b = 0; b < 2 && v; b++) {	/* v == p == NULL: the snapshot is dropped (a writer that failed elsewhere still collects) */
 		const char *src = (const char *)c->snap_host[b];
 		for (int64_t q = 0; q < c->count[sd]; q++) {
 			const int64_t solver_row = c->first[sd] + q;
@@ -1543,7 +1544,7 @@ extern "C" int blz_snapshot_wait(blz_ctx *c, uint64_t *v, uint64_t *p, int64_t *
 	}
 	if (iterations)
 		*iterations = c->snap_iterations;
-	c->snap_pending = false;
+	c->snap_pending.store(false, std::memory_order_release);
 	return BLZ_OK;
 }
 
@@ -1616,4 +1617,11 @@ extern "C" int blz_exchange_pieces(const blz_ctx *c, int transpose)
 		return -1;
 	const int t = transpose ? 1 : 0;
 	return c->short_side[t] ? 0 : (int)c->csr[t].size();
+}
+
+extern "C" int blz_exchange_pieces_for(const blz_ctx *c, int64_t mrows, int64_t mcols, int64_t nnz, int nranks)
+{
+	if (!c || nranks < 1)
+		return -1;
+	return prep_params(c, mrows, mcols, nnz, nranks).K;
 }

@@ -82,7 +82,7 @@ struct KernelCfg {
 	void *mfma_img;		/* device scratch for the coefficient digits in MFMA fragment order (ortho_mfma_image_bytes()) */
 	int panel;		/* 1: slabs whose operand has hot block rows run k_spmv_panel; BLZ_NO_PANEL=1 turns it off */
 	int staged;		/* 1: slabs with a plan run k_spmv_staged; BLZ_NO_STAGE=1 keeps the round-1 kernels (A/B) */
-	int pair;		/* 1: two words per lane in the staged SpMV at n = 16 (BLZ_NO_PAIR=1 turns it off) */
+	int pair;		/* 1: two words per lane (16-byte gathers) in the staged SpMV at n = 16 and n = 8, 64-bit words (BLZ_NO_PAIR=1: off) */
 	int stage_dyn;		/* -1: dynamic rows in the staged SpMV by plan; 0 / 1: forced off / on (BLZ_STAGE_DYN, read once) */
 	int stage_u;		/* 0: gathers in flight per lane of the staged SpMV chosen by the slab's plan; 4 / 8: forced (BLZ_STAGE_U, read once) */
 };

@@ -1291,10 +1291,13 @@ k_spmv_staged(const u32 *__restrict__ rp, const u32 *__restrict__ ci, const u32 
 		ds.finish(red, partial, m, (int)blockIdx.x);
 }
 
-/* two words per lane where the block row is 16 u64 words (see staged_accumulate2); BLZ_NO_PAIR=1 keeps one word per lane */
+/* two words per lane where the block row is 16 or 8 u64 words (see staged_accumulate2); BLZ_NO_PAIR=1 keeps one word per lane.
+ * Measured (profiles/r03_synth5q_pair_lanes.txt, r03_pair_lanes_n8.txt): config-5 quarter shape, n = 16: 12.46 / 11.67 ->
+ * 11.42 / 11.21 ms per product; relat9 shape, n = 8, first product (the second carries the inner products and keeps one
+ * word per lane): 624 -> 617 us. */
 static inline bool spmv_pair_lanes(const KernelCfg &c)
 {
-	return c.pair && c.n == 16 && c.word == 8;
+	return c.pair && c.word == 8 && (c.n == 16 || c.n == 8);
 }
 
 /* Host side of the plan, made once per slab at upload (blz_api.hip): tile height, staging window, grid density and the
@@ -1311,7 +1314,7 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, bool al
 	if (spmv_split_log2(c, D.rows, D.nnz) != 0)	/* few long rows shared by adjacent groups: k_spmv */
 		return;
 	/* lanes per row: G, or 8 lanes of two words at n = 16 (8 rows per wavefront); the heuristics below go by the row width G */
-	const bool pair = spmv_pair_lanes(c) && !(c.stage_dyn == 1 && allow_dyn);
+	const bool pair = spmv_pair_lanes(c) && allow_dyn && c.stage_dyn != 1;	/* (a slab that carries the inner products keeps one word per lane) */
 	D.st_pair = pair;
 	{
 		/* Measured on MI355X (gpurun_out r2a..r2g, profiles/r02_staged_*): staging pays where the stream is a large
@@ -1327,7 +1330,7 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, bool al
 		if (!(e && e[0] == '1') && a >= 12.0 && a < 32.0)
 			return;
 	}
-	const int GPW = pair ? 8 : 64 / G, NS = (D.val && !D.palette) ? 2 : 1;
+	const int GPW = pair ? 128 / G : 64 / G, NS = (D.val && !D.palette) ? 2 : 1;
 	const double avg = D.kept_mean >= 0.0 ? D.kept_mean : (double)D.nnz / (double)D.rows;
 	/* Rows of a few entries (relat9 shape, 3.15 per row, profiles/r02_exp_staged_sweep_relat9.txt): a batch of 8 gathers
 	 * per lane is mostly switched-off slots, and 16 wavefronts per CU with the larger window beat 32 with the smaller one
@@ -1337,7 +1340,7 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, bool al
 	int per_cu = c.spmv_blocks_per_cu > 0 ? c.spmv_blocks_per_cu : (((avg >= 12.0 || few) && G < 16) ? (D.uneven && !few ? 6 : 4) : 8);
 	/* two words per lane: 8 rows per wavefront keep the fabric busy with 16 wavefronts per CU and the larger window (config-5
 	 * quarter shape, per product: 11.85 / 11.17 ms at 8 workgroups per CU, 11.42 / 11.21 at 4, 14.08 / 11.99 at 6) */
-	if (pair && c.spmv_blocks_per_cu <= 0)
+	if (pair && G == 16 && c.spmv_blocks_per_cu <= 0)
 		per_cu = 4;
 	/* LDS: 4 wavefronts x 2 buffers x capw entries x 4 B per block (x NS streams); 160 KB per CU */
 	int capw = (per_cu <= 4 ? 1024 : 512) / NS;
@@ -1421,11 +1424,17 @@ static void staged_launch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y,
 	hipLaunchKernelGGL((k_spmv_staged<W, G, MERS, DOT, VALS, UU, DD>), dim3((unsigned)blocks), dim3(BLOCK), lds, s, A.row_ptr, \
 			   (const u32 *)A.col_idx, A.val, A.palette, X, Y, Vd, (long long)A.rows, c.n, A.st_tr, A.st_capw, accum, \
 			   A.heavy_thr, c.m, partial, xt, ctl)
-	if constexpr (G == 16 && !DOT && sizeof(W) == 8) {
-		if (A.st_pair) {	/* 8 lanes of two words per row */
-			hipLaunchKernelGGL((k_spmv_staged<W, 8, MERS, false, VALS, 8, false, 2>), dim3((unsigned)blocks), dim3(BLOCK), lds, s,
-					   A.row_ptr, (const u32 *)A.col_idx, A.val, A.palette, X, Y, Vd, (long long)A.rows, c.n, A.st_tr, A.st_capw,
-					   accum, A.heavy_thr, c.m, partial, xt, ctl);
+	if constexpr ((G == 16 || G == 8) && !DOT && sizeof(W) == 8) {
+		if (A.st_pair) {	/* G / 2 lanes of two words per row */
+#define STAGED_PAIR(UU)                                                                                                 \
+	hipLaunchKernelGGL((k_spmv_staged<W, G / 2, MERS, false, VALS, UU, false, 2>), dim3((unsigned)blocks), dim3(BLOCK), lds, s, \
+			   A.row_ptr, (const u32 *)A.col_idx, A.val, A.palette, X, Y, Vd, (long long)A.rows, c.n, A.st_tr, A.st_capw, \
+			   accum, A.heavy_thr, c.m, partial, xt, ctl)
+			if (G == 16 || A.st_deep)
+				STAGED_PAIR(8);
+			else
+				STAGED_PAIR(4);
+#undef STAGED_PAIR
 			return;
 		}
 	}

@@ -330,14 +330,24 @@ static void *checkpoint_writer(void *arg)
 	}
 	int64_t its = 0;
 	int rc = (writer.v && writer.p) ? BLZ_OK : BLZ_ENOMEM;
-	for (int g = 0; g < gpus && rc == BLZ_OK; g++)
-		rc = blz_snapshot_wait(team.ctx[g], writer.v, writer.p, &its);
+	char why[512] = "";
+	/* every context's snapshot is collected whatever happens -- a context left with one in flight refuses the next
+	 * checkpoint, and a transient failure here must not end the solve: after the first failure the
+	 * remaining ones are dropped (NULL buffers) */
+	for (int g = 0; g < gpus; g++) {
+		const int r = rc == BLZ_OK ? blz_snapshot_wait(team.ctx[g], writer.v, writer.p, &its)
+					   : blz_snapshot_wait(team.ctx[g], NULL, NULL, NULL);
+		if (r != BLZ_OK && rc == BLZ_OK) {
+			rc = r;
+			snprintf(why, sizeof why, "%s", blz_last_error());
+		}
+	}
 	if (rc == BLZ_OK)
 		rc = blz_checkpoint_save("lanczos_modp.ckpt", prime, (int)n, right_kernel, writer.nrows, its, writer.v, writer.p);
 	if (rc == BLZ_OK)
 		printf("\n		>> Snapshot written to lanczos_modp.ckpt (iteration %" PRId64 ")\n", its);
 	else
-		fprintf(stderr, "\ncheckpoint NOT written: %s\n", rc == BLZ_ENOMEM ? "out of memory" : blz_last_error());
+		fprintf(stderr, "\ncheckpoint NOT written: %s\n", rc == BLZ_ENOMEM ? "out of memory" : (why[0] ? why : blz_last_error()));
 	fflush(stdout);
 	writer.busy = false;
 	return NULL;

@@ -408,6 +408,9 @@ class Context:
         check(lib().blz_comm_info(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def exchange_pieces_for(self, mrows, mcols, nnz, nranks):
+        return int(lib().blz_exchange_pieces_for(self.h, C.c_int64(mrows), C.c_int64(mcols), C.c_int64(nnz), C.c_int(nranks)))
+
     def exchange_pieces(self, transpose):
         return int(lib().blz_exchange_pieces(self.h, C.c_int(1 if transpose else 0)))
 

@@ -324,8 +324,10 @@ int blz_final_check(blz_ctx *ctx, int *v_nonzero, int *vtm_zero);
  * rank's rows on a stream of their own and returns; the GPU pauses for the transfer only and the caller goes on
  * iterating.  blz_snapshot_wait blocks until the copies have landed and writes this rank's rows into v and p (whole
  * blocks of rows(V) x n words, original numbering; other ranks' rows untouched).  It may be called from ANOTHER host
- * thread (the checkpoint writer) while the owner is inside blz_iterate -- the one exception to one thread per handle.
- * One snapshot in flight per context. */
+ * thread (the checkpoint writer) while the owner is inside blz_iterate -- the one exception to one thread per handle
+ * (the in-flight mark is an atomic: begin in the owner's thread sees a wait that finished in the writer's).
+ * v == p == NULL drops the snapshot: a writer that has failed (memory, one rank's copy) must still collect from EVERY
+ * context, or their next blz_snapshot_begin is refused.  One snapshot in flight per context. */
 int blz_snapshot_begin(blz_ctx *c);
 int blz_snapshot_wait(blz_ctx *c, uint64_t *v, uint64_t *p, int64_t *iterations);
 
@@ -364,6 +366,9 @@ int blz_comm_info(const blz_ctx *ctx, int *nranks_seen, int *rank_seen);
 /* pieces the exchange of product `transpose`'s operand (and the product itself) is cut into; 0 in the short-side form,
  * where nothing is gathered */
 int blz_exchange_pieces(const blz_ctx *ctx, int transpose);
+/* the number of pieces this context would have a matrix of that shape prepared in for nranks ranks (what blz_prepare_for
+ * passes to blz_prepare): for callers that prepare a rank's share themselves (blz_prepare_rank) */
+int blz_exchange_pieces_for(const blz_ctx *ctx, int64_t mrows, int64_t mcols, int64_t nnz, int nranks);
 
 #ifdef __cplusplus
 }

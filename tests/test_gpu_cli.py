@@ -233,3 +233,15 @@ def test_asynchronous_snapshot_is_the_state_at_the_moment_it_was_begun():
             th.join(60)
             assert got["its"] == 5 and np.array_equal(got["v"], at5["v"]) and np.array_equal(got["p"], at5["p"])
             assert np.array_equal(ctx.get_block(blz.V), at12["v"]) and np.array_equal(ctx.get_block(blz.P), at12["p"])
+            # a snapshot can be DROPPED (NULL buffers: what the CLI's writer does for the other contexts once one has failed),
+            # from another thread; the context then takes the next one
+            ctx.snapshot_begin()
+            rcs = []
+            th = threading.Thread(target=lambda: rcs.append(blz.lib().blz_snapshot_wait(ctx.h, None, None, None)))
+            th.start()
+            th.join(60)
+            assert rcs == [0]
+            ctx.snapshot_begin()
+            assert ctx.snapshot_wait()[2] == 12
+            with pytest.raises(blz.BlzError):
+                ctx.snapshot_wait()                        # nothing in flight

@@ -51,6 +51,13 @@ def test_cli_with_several_gpus_reproduces_the_reference_hashes(tmp_path, gpus):
         assert hashlib.sha256(open(out, "rb").read()).hexdigest() == c["out_sha256"], tag
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def _ranks(nranks, fn):
     """run fn(rank) in one thread per rank (ctypes releases the GIL: the ranks really meet inside RCCL)"""
     errs = [None] * nranks
@@ -148,13 +155,54 @@ def test_bench_under_torch_distributed_run_checks_itself(world):
         pytest.skip(f"{world} GPUs asked, {NDEV} visible")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-                        "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
                         "--workload", "tiny", "--steps", "5", "--warmup", "1", "--cpu-seconds", "0"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == world and d["value"] and d["sharded_equals_single_gpu"]["equal"] is True
+
+
+@need2
+@pytest.mark.parametrize("world", [g for g in (2, 8) if g <= max(NDEV, 2)])
+def test_bench_starts_its_own_ranks(world):
+    """`python bench.py --gpus N` with no launcher around it (how the driver starts the N = 1 run): the parent starts one
+    process per GPU itself and relays their line.  The line must say how many ranks RCCL saw, how each exchange was cut and
+    what every collective cost."""
+    if world > NDEV:
+        pytest.skip(f"{world} GPUs asked, {NDEV} visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--workload", "tiny", "--steps", "5",
+                        "--warmup", "1", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["value"] and d["sharded_equals_single_gpu"]["equal"] is True
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks_seen"] == world
+    assert mg["pieces"]["spmv1"] >= 1 and mg["pieces"]["spmv2"] >= 1
+    assert mg["collectives"]["allreduce"]["calls_per_step"] == 1
+    assert d["roofline"]["traffic"] is None            # no PMC run of this (workload, N) is committed
+
+
+def test_bench_per_rank_set_up_path_on_one_rank():
+    """Config 5's way of starting (`bench.py --gpus 8 --workload synth5`): every rank generates its own rows and columns
+    (blz_synth_coo_part), prepares from that share alone (blz_prepare_rank) and nobody holds the whole matrix.  Run here on a
+    small matrix of the same kind with ONE rank under the launcher and the exchange code forced on; the line must say that the
+    reference's in-loop invariants hold on the n x n operands after the measured iterations."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BLZ_BENCH_PER_RANK="1", BLZ_FORCE_COMM="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                        "--workload", "tiny5", "--steps", "4", "--warmup", "1", "--cpu-seconds", "0", "--ref-iterations", "0"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["value"] and d["sharded_equals_single_gpu"]["invariants_hold"] is True
+    assert "every rank generates" in d["data"]
+    assert d["multi_gpu"]["collectives"]["allgather_v"]["calls_per_step"] >= 1
 
 
 def test_bench_shared_set_up_path_on_one_rank():
@@ -164,7 +212,7 @@ def test_bench_shared_set_up_path_on_one_rank():
     wire.  The line must say that the run equals a plain single-GPU solve."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BLZ_BENCH_SHARE="1", BLZ_FORCE_COMM="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
-                        "--master-addr", "127.0.0.1", "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1",
                         "--workload", "tiny", "--steps", "5", "--warmup", "1", "--cpu-seconds", "0", "--ref-iterations", "0"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -172,3 +220,8 @@ def test_bench_shared_set_up_path_on_one_rank():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] and d["sharded_equals_single_gpu"]["equal"] is True
     assert d["kernels"]["allgather_v"]["launches"] > 0 and d["kernels"]["allreduce"]["launches"] > 0
+    # the N > 1 diagnostics, on the 1-rank communicator: what RCCL says it has, the pieces, a time per collective
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks_seen"] == 1 and mg["pieces"]["spmv1"] >= 1
+    assert mg["collectives"]["allgather_v"]["ms_per_call"] > 0 and mg["collectives"]["allreduce"]["calls_per_step"] == 1
+    assert mg["exposed_exchange_ms_per_step"] >= 0 and mg["compute_ms_per_step"] > 0

@@ -389,16 +389,18 @@ def test_staged_matrix_stream_against_oracle(monkeypatch, n, p, kind, capw, rpg)
 
 
 @pytest.mark.parametrize("capw,rpg", [(None, None), ("64", "1"), ("128", "3"), ("4096", "8")])
-@pytest.mark.parametrize("p,kind", [(P61, "ones"), (P61, "packed"), ((1 << 62) - 57, "array"), (2305843009213693907, "packed")])
-def test_two_words_per_lane_at_n16_against_oracle(monkeypatch, p, kind, capw, rpg):
+@pytest.mark.parametrize("n,p,kind", [(16, P61, "ones"), (16, P61, "packed"), (16, (1 << 62) - 57, "array"), (12, 2305843009213693907, "packed"),
+                                      (8, P61, "packed"), (8, (1 << 62) - 57, "array"), (8, P61, "ones")])
+def test_two_words_per_lane_at_n16_against_oracle(monkeypatch, n, p, kind, capw, rpg):
     """Round 3: at n = 16 (64-bit words) a block row is gathered by 8 lanes of two words (16 bytes per lane, 8 rows per
     wavefront) instead of 16 lanes of one.  Same sums per word, so the same words as the oracle and as the one-word form
-    (BLZ_NO_PAIR=1): every value mode, windows that rows overflow, an outlier row, both orientations, whole iterations."""
+    (BLZ_NO_PAIR=1): every value mode, windows that rows overflow, an outlier row, both orientations, whole iterations.
+    n = 12 is padded to 16 in HBM; n = 8 (4 lanes of 16 bytes per 64-byte row) pairs the first product of an
+    iteration only -- the second carries the inner products and keeps one word per lane."""
     monkeypatch.setenv("BLZ_STAGE_ALWAYS", "1")
     if capw:
         monkeypatch.setenv("BLZ_STAGE_CAPW", capw)
         monkeypatch.setenv("BLZ_STAGE_RPG", rpg)
-    n = 16
     rng = np.random.default_rng(len(kind) * 31 + p % 97)
     nr, nc, nz = 8000, 7700, 160000
     ii, jj = rng.integers(0, nr, nz), rng.integers(0, nc, nz)
