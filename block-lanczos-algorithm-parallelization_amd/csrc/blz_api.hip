@@ -401,9 +401,10 @@ extern "C" void blz_destroy(blz_ctx *c)
 
 extern "C" int blz_word_bytes(const blz_ctx *c) { return c ? c->cfg.word : 0; }
 
-static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D, int64_t hot_rows = 0, bool dot_slab = false)
+static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D, int64_t hot_rows = 0, bool dot_slab = false, double locality = 1.0)
 {
 	free_csr(D);
+	D.locality = locality;
 	D.rows = H.rows;
 	D.cols = H.cols;
 	D.nnz = H.nnz;
@@ -667,7 +668,7 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 		if (K == 1) {
 			/* product t gathers block rows by the column index of its slab: columns of M for t = 0, rows of M for t = 1 */
 			const int64_t hot_t = c->cfg.panel ? P->hot[t == 0 ? 1 : 0] : 0;
-			rc = upload_csr(c, slab, c->csr[t][0], hot_t, dot_slab);
+			rc = upload_csr(c, slab, c->csr[t][0], hot_t, dot_slab, nranks == 1 ? c->locality[t] : 1.0);
 			const char *xe = getenv("BLZ_XCD_RANGES");	/* 0 / 1 force it off / on (A/B) */
 			/* (an operand of a few MB sits in every L2 anyway: nothing to separate) */
 			const bool big = (double)slab.cols * c->cfg.n * c->cfg.word > 8e6;

@@ -1327,7 +1327,14 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, bool al
 		/* (the same holds at 128-byte block rows: GL7d19 shape at n = 16, rows of 19.5: 722 -> 779 us staged, while the
 		 * config-5 quarter shape, rows of 40, gains: 13.1 -> 12.4 ms -- there 130 M stream requests per launch become
 		 * 16 M lines, profiles/r02_synth5q_pmc.txt.  The boundary is put at 32 entries.) */
-		if (!(e && e[0] == '1') && a >= 12.0 && a < 32.0)
+		/* Round 3: ... unless the gathers mostly HIT.  With the renumbering's sampled footprint below 0.3 lines per entry
+		 * (a banded or otherwise local matrix) the product is paced by the kernel, not by the fabric, and there the staged
+		 * form (with 16-byte lanes) is the quicker one whatever the row length -- band matrix, 2 M x 2 M, rows of 20, first
+		 * product: 535 us as k_spmv, 332 us staged (profiles/r03_exp_band_staged_always.txt; round 2 saw 516 -> 369 on the
+		 * GL7d19 shape with all entries in a band) -- except on heavy-tailed row lengths, where it loses (`nfs` workload: 853
+		 * against 664 us).  The product that carries the inner products gains nothing from it (406 against 404 us). */
+		const bool local = allow_dyn && D.locality < 0.3 && !D.uneven;
+		if (!(e && e[0] == '1') && a >= 12.0 && a < 32.0 && !local)
 			return;
 	}
 	const int GPW = pair ? 128 / G : 64 / G, NS = (D.val && !D.palette) ? 2 : 1;

@@ -388,6 +388,33 @@ def test_staged_matrix_stream_against_oracle(monkeypatch, n, p, kind, capw, rpg)
                 assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
 
 
+@pytest.mark.parametrize("n,p", [(8, P61), (16, P61), (4, 2147483647)])
+def test_a_local_matrix_takes_the_staged_form_by_itself(n, p):
+    """Round 3: rows of ~20 entries normally keep k_spmv, but when the renumbering's sample finds the gathers mostly hitting
+    (a band matrix: < 0.3 lines per entry) the first product of an iteration runs the staged form.  No switch set here: the
+    plan decides; the words must be the oracle's for a banded matrix in its own order and for the same matrix scrambled."""
+    rng = np.random.default_rng(n)
+    R = C = 40000
+    per, band = 20, 400
+    i = np.repeat(np.arange(R), per)
+    j = (i + rng.integers(-band // 2, band // 2, size=R * per)) % C
+    x = (rng.choice(np.array([1, 2, 3, 2 ** 32 - 1], dtype=np.uint64), size=R * per) % p).astype(np.uint32)
+    pr, pc = rng.permutation(R), rng.permutation(C)
+    for M in (blz.Matrix(R, C, i, j, x), blz.Matrix(R, C, pr[i], pc[j], x)):
+        Mo = as_orc(M)
+        want = orc.block_lanczos(Mo, n, p, stop_after=4)
+        with blz.Context(p, n) as ctx:
+            ctx.set_matrix(M, False)
+            ctx.init_v()
+            ctx.iterate(4)
+            assert np.array_equal(ctx.get_block(blz.V), want["v"]) and np.array_equal(ctx.get_block(blz.P), want["p"])
+            # and both products on their own (the reference's tmp holds the new v after an iteration, so it is not compared above)
+            xin = (np.arange(ctx.rows(blz.V) * n, dtype=np.uint64) * 2654435761 + 7) % p
+            ctx.set_block(blz.V, xin)
+            ctx.spmv(True, blz.V, blz.TMP)
+            assert np.array_equal(ctx.get_block(blz.TMP), orc.spmv(Mo, xin, True, n, p))
+
+
 @pytest.mark.parametrize("capw,rpg", [(None, None), ("64", "1"), ("128", "3"), ("4096", "8")])
 @pytest.mark.parametrize("n,p,kind", [(16, P61, "ones"), (16, P61, "packed"), (16, (1 << 62) - 57, "array"), (12, 2305843009213693907, "packed"),
                                       (8, P61, "packed"), (8, (1 << 62) - 57, "array"), (8, P61, "ones")])
