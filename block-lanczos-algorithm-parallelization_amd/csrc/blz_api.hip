@@ -22,6 +22,9 @@
 #include <cstring>
 #include <vector>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 
 #include "blz_internal.h"
 #include "blz_kernels.h"
@@ -94,6 +97,49 @@ int rccl_load()
 
 enum { PK_SPMV1 = 0, PK_SPMV2, PK_DOT, PK_SEMI, PK_ORTHO, PK_AG_V, PK_AG_T, PK_AR, PK_RS, PK_COUNT };
 
+/*
+ * Loopback communicator (round 3): several contexts of ONE process on ONE device, one host thread each, exchange through
+ * this object instead of RCCL (which refuses two ranks on one GPU).  Everything else of the multi-rank path -- the slabs,
+ * the gathered layouts, the piece pipeline on two streams with its events, the landing buffers, what a batch does past
+ * the stop -- is the production code, so the one-GPU boxes this was developed on can run blz_iterate with 2, 3 or 8 real
+ * ranks' worth of sums against the oracle.  A collective is: post my buffers and an event on my stream; meet the other
+ * threads; make my stream wait for their events and enqueue my copies / sums from THEIR send buffers; record a second
+ * event; meet again; make my stream wait for everybody's second event (nobody overwrites a buffer somebody still reads).
+ * Not a transport: the data never leaves the device.
+ */
+struct blz_loop_group {
+	int nranks = 0;
+	std::mutex mu;
+	std::condition_variable cv;
+	int arrived = 0;
+	unsigned long long generation = 0;
+	bool broken = false;
+	int timeout_s = 120;		/* BLZ_LOOP_TIMEOUT_S at creation (tests of the time-out itself) */
+	std::vector<const void *> send;
+	std::vector<hipEvent_t> ready, done;
+	/* all ranks meet; false after the time-out or once any rank has given up */
+	bool meet()
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		if (broken)
+			return false;
+		const unsigned long long gen = generation;
+		if (++arrived == nranks) {
+			arrived = 0;
+			generation++;
+			cv.notify_all();
+			return true;
+		}
+		if (!cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return generation != gen || broken; }))
+			broken = true;
+		if (broken) {
+			cv.notify_all();
+			return false;
+		}
+		return true;
+	}
+};
+
 struct ProfSpan {
 	int cls;
 	hipEvent_t a, b;
@@ -132,6 +178,8 @@ struct blz_ctx {
 	DevCtl host_ctl{};
 	DevCtl *ctl_pinned = nullptr, *ctl_pinned_dev = nullptr;	/* host-mapped landing place of the control words */
 	ncclComm_t comm = nullptr;
+	blz_loop_group *loop = nullptr;		/* loopback communicator instead of RCCL (contexts of one process on one device) */
+	hipEvent_t loop_ready = nullptr, loop_done = nullptr;
 	/* perm[side][original row] = row in the solver's numbering (empty = identity); inv is the inverse */
 	std::vector<int32_t> perm[2], inv[2];
 	bool reorder = true;		/* BLZ_NO_REORDER=1 keeps the file's numbering */
@@ -355,6 +403,8 @@ extern "C" void blz_destroy(blz_ctx *c)
 		hipGraphExecDestroy(c->iter_graph);
 	if (c->comm && g_rccl.CommDestroy)
 		g_rccl.CommDestroy(c->comm);
+	if (c->loop_ready) hipEventDestroy(c->loop_ready);
+	if (c->loop_done) hipEventDestroy(c->loop_done);
 	for (int t = 0; t < 2; t++)
 		for (auto &A : c->csr[t])
 			free_csr(A);
@@ -1076,18 +1126,93 @@ extern "C" int blz_init_v(blz_ctx *c)
 
 static inline bool exchanging(const blz_ctx *c)
 {
-	return !c->external_exchange && (c->nranks > 1 || (c->force_comm && c->comm));
+	return !c->external_exchange && (c->nranks > 1 || (c->force_comm && (c->comm || c->loop)));
 }
 
 /* where k_dot_finalize puts this rank's sums: straight into `small` on one rank, into the send buffer otherwise */
 static inline u64 *dot_out(blz_ctx *c);
 
+/* ---- the four collectives of the solver, over RCCL or over the loopback group ---- */
+
+enum { LOOP_GATHER = 0, LOOP_SUM64 = 1, LOOP_SUM64_SEGMENT = 2, LOOP_SUM32 = 3 };
+
+/* one loopback collective of rank c->rank on stream st: `count` = bytes per rank (gather) or words (sums) */
+static int loop_collective(blz_ctx *c, int kind, const void *send, void *recv, size_t count, hipStream_t st)
+{
+	blz_loop_group *g = c->loop;
+	const int r = c->rank, N = g->nranks;
+	g->send[(size_t)r] = send;
+	HIPCHK(hipEventRecord(c->loop_ready, st));
+	g->ready[(size_t)r] = c->loop_ready;
+	g->done[(size_t)r] = c->loop_done;
+	if (!g->meet())
+		return blz_fail(BLZ_ECOMM, "loopback communicator: a rank did not arrive (or gave up)");
+	for (int q = 0; q < N; q++)
+		if (q != r)
+			HIPCHK(hipStreamWaitEvent(st, g->ready[(size_t)q], 0));
+	if (kind == LOOP_GATHER) {
+		for (int q = 0; q < N; q++)
+			HIPCHK(launch_copy(c->cfg, (char *)recv + (size_t)q * count, g->send[(size_t)q], count, st));
+	} else {
+		const void *src[BLZ_LOOP_MAX_RANKS];
+		for (int q = 0; q < N; q++)
+			src[q] = kind == LOOP_SUM64_SEGMENT ? (const void *)((const u64 *)g->send[(size_t)q] + (size_t)r * count) : g->send[(size_t)q];
+		HIPCHK(launch_sum_buffers(src, N, recv, (long long)count, kind == LOOP_SUM32 ? 4 : 8, st));
+	}
+	HIPCHK(hipEventRecord(c->loop_done, st));
+	if (!g->meet())
+		return blz_fail(BLZ_ECOMM, "loopback communicator: a rank did not arrive (or gave up)");
+	for (int q = 0; q < N; q++)
+		if (q != r)
+			HIPCHK(hipStreamWaitEvent(st, g->done[(size_t)q], 0));
+	return BLZ_OK;
+}
+
+static int coll_allgather(blz_ctx *c, const void *send, void *recv, size_t bytes, hipStream_t st)
+{
+	if (c->loop)
+		return loop_collective(c, LOOP_GATHER, send, recv, bytes, st);
+	if (!c->comm)
+		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
+	NCCLCHK(g_rccl.AllGather(send, recv, bytes, ncclUint8, c->comm, st));
+	return BLZ_OK;
+}
+
+static int coll_allreduce_u64(blz_ctx *c, const void *send, void *recv, size_t words, hipStream_t st)
+{
+	if (c->loop)
+		return loop_collective(c, LOOP_SUM64, send, recv, words, st);
+	if (!c->comm)
+		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
+	NCCLCHK(g_rccl.AllReduce(send, recv, words, ncclUint64, ncclSum, c->comm, st));
+	return BLZ_OK;
+}
+
+static int coll_allreduce_i32(blz_ctx *c, const void *send, void *recv, size_t words, hipStream_t st)
+{
+	if (c->loop)
+		return loop_collective(c, LOOP_SUM32, send, recv, words, st);
+	if (!c->comm)
+		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
+	NCCLCHK(g_rccl.AllReduce(send, recv, words, ncclInt32, ncclSum, c->comm, st));
+	return BLZ_OK;
+}
+
+/* recv[i] = sum over the ranks of send_q[rank * words + i] */
+static int coll_reduce_scatter_u64(blz_ctx *c, const void *send, void *recv, size_t words, hipStream_t st)
+{
+	if (c->loop)
+		return loop_collective(c, LOOP_SUM64_SEGMENT, send, recv, words, st);
+	if (!c->comm)
+		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
+	NCCLCHK(g_rccl.ReduceScatter(send, recv, words, ncclUint64, ncclSum, c->comm, st));
+	return BLZ_OK;
+}
+
 static int allreduce_dots(blz_ctx *c)
 {
 	if (!exchanging(c))
 		return BLZ_OK;
-	if (!c->comm)
-		return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
 	Span sp(c, PK_AR);
 	/* residues < p and nranks * p <= 2^64 (checked in blz_set_matrix): the u64 sum cannot wrap; the
 	 * semi_inverse kernel reduces it mod p.  (mpi/lanczos_modp.c:1209-1247 does this by hand.)
@@ -1095,9 +1220,7 @@ static int allreduce_dots(blz_ctx *c)
 	 * collective is enqueued by the host whatever the stop flag says, and the iterations a batch enqueues past the stop
 	 * would leave raw sums (up to nranks * (p - 1)) in `small` -- the semi-inverse kernel, the one that turns them
 	 * into residues, is a no-op by then.  It reads dot_recv and writes `small` only while the flag is down. */
-	NCCLCHK(g_rccl.AllReduce(c->dot_send, c->dot_recv, (size_t)2 * c->cfg.n * c->cfg.n, ncclUint64, ncclSum, c->comm,
-				 c->stream));
-	return BLZ_OK;
+	return coll_allreduce_u64(c, c->dot_send, c->dot_recv, (size_t)2 * c->cfg.n * c->cfg.n, c->stream);
 }
 
 static inline u64 *dot_out(blz_ctx *c) { return exchanging(c) ? c->dot_send : c->small; }
@@ -1128,12 +1251,11 @@ static int enqueue_product(blz_ctx *c, int transpose, int src, int dst, bool wit
 			HIPCHK(launch_spmv(c->cfg, c->csr_short[transpose], slab_ptr(c, src), c->part, 0, c->ctl, c->stream));
 		}
 		if (xchg) {
-			if (!c->comm)
-				return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
 			{
 				Span sp(c, PK_RS);
-				NCCLCHK(g_rccl.ReduceScatter(c->part, c->rs_recv, (size_t)c->stride[rs_t] * c->cfg.n, ncclUint64, ncclSum,
-							     c->comm, c->stream));
+				int rc_ = coll_reduce_scatter_u64(c, c->part, c->rs_recv, (size_t)c->stride[rs_t] * c->cfg.n, c->stream);
+				if (rc_ != BLZ_OK)
+					return rc_;
 			}
 			/* out of place and stop-aware: past the stop `part` is stale (possibly the OTHER product's), the collective
 			 * runs all the same, and slab[dst] must keep the last real product (blz_final_check reads TMP) */
@@ -1143,7 +1265,7 @@ static int enqueue_product(blz_ctx *c, int transpose, int src, int dst, bool wit
 	}
 	const int K = (int)c->csr[transpose].size(), sd = side_of(src);
 	if (xchg) {
-		if (!c->comm)
+		if (!c->comm && !c->loop)
 			return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
 		/* the exchange may start once everything enqueued so far (the producer of `src`, and every earlier
 		 * reader of the gathered buffer it overwrites) has run */
@@ -1154,9 +1276,10 @@ static int enqueue_product(blz_ctx *c, int transpose, int src, int dst, bool wit
 		for (int k = 0; k < K; k++) {
 			{
 				Span sp(c, src == BLZ_V ? PK_AG_V : PK_AG_T, c->xstream);
-				NCCLCHK(g_rccl.AllGather((char *)c->slab[src] + (size_t)k * piece,
-							 recv + (size_t)k * c->nranks * piece, piece, ncclUint8, c->comm,
-							 c->xstream));
+				int rc_ = coll_allgather(c, (char *)c->slab[src] + (size_t)k * piece, recv + (size_t)k * c->nranks * piece, piece,
+							 c->xstream);
+				if (rc_ != BLZ_OK)
+					return rc_;
 			}
 			HIPCHK(hipEventRecord(c->ev_piece[(size_t)k], c->xstream));
 		}
@@ -1374,10 +1497,12 @@ extern "C" int blz_final_check(blz_ctx *c, int *v_nonzero, int *vtm_zero)
 	HIPCHK(launch_any_nonzero(c->cfg, slab_ptr(c, BLZ_V), c->count[0] * c->cfg.n, &c->ctl->flag_v_nonzero, c->stream));
 	HIPCHK(launch_any_nonzero(c->cfg, slab_ptr(c, BLZ_TMP), c->count[1] * c->cfg.n, &c->ctl->flag_t_nonzero, c->stream));
 	if (c->nranks > 1 && !c->external_exchange) {
-		if (!c->comm)
-			return blz_fail(BLZ_ECOMM, "nranks > 1 but blz_comm_init was not called");
-		NCCLCHK(g_rccl.AllReduce(&c->ctl->flag_v_nonzero, &c->ctl->flag_v_nonzero, 2, ncclInt32, ncclSum, c->comm,
-					 c->stream));
+		/* out of place (the sums land in dot_recv, idle at this point, and are copied back): the loopback communicator
+		 * reads the other ranks' send buffers while they write their own results */
+		int rc_ = coll_allreduce_i32(c, &c->ctl->flag_v_nonzero, c->dot_recv, 2, c->stream);
+		if (rc_ != BLZ_OK)
+			return rc_;
+		HIPCHK(hipMemcpyAsync(&c->ctl->flag_v_nonzero, c->dot_recv, 2 * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
 	}
 	int rc = fetch_ctl(c);
 	if (rc != BLZ_OK)
@@ -1601,7 +1726,10 @@ extern "C" int blz_comm_info(const blz_ctx *c, int *nranks_seen, int *rank_seen)
 	if (!c)
 		return blz_fail(BLZ_EINVAL, "blz_comm_info: NULL context");
 	int cnt = -1, rk = -1;
-	if (c->comm) {
+	if (c->loop) {
+		cnt = c->loop->nranks;
+		rk = c->rank;
+	} else if (c->comm) {
 		NCCLCHK(g_rccl.CommCount(c->comm, &cnt));
 		NCCLCHK(g_rccl.CommUserRank(c->comm, &rk));
 	}
@@ -1625,4 +1753,43 @@ extern "C" int blz_exchange_pieces_for(const blz_ctx *c, int64_t mrows, int64_t 
 	if (!c || nranks < 1)
 		return -1;
 	return prep_params(c, mrows, mcols, nnz, nranks).K;
+}
+
+/* ---- loopback communicator: several contexts of one process on one device (tests of the multi-rank path on one GPU) ---- */
+
+extern "C" int blz_loop_group_create(int nranks, blz_loop_group **out)
+{
+	if (!out || nranks < 1 || nranks > BLZ_LOOP_MAX_RANKS)
+		return blz_fail(BLZ_EINVAL, "blz_loop_group_create: 1 .. %d ranks", BLZ_LOOP_MAX_RANKS);
+	blz_loop_group *g = new blz_loop_group();
+	g->nranks = nranks;
+	if (const char *e = getenv("BLZ_LOOP_TIMEOUT_S"))
+		if (atoi(e) >= 1)
+			g->timeout_s = atoi(e);
+	g->send.assign((size_t)nranks, nullptr);
+	g->ready.assign((size_t)nranks, nullptr);
+	g->done.assign((size_t)nranks, nullptr);
+	*out = g;
+	return BLZ_OK;
+}
+
+extern "C" void blz_loop_group_destroy(blz_loop_group *g)
+{
+	delete g;
+}
+
+extern "C" int blz_comm_init_loopback(blz_ctx *c, blz_loop_group *g, int rank)
+{
+	if (!c || !g || rank < 0 || rank >= g->nranks)
+		return blz_fail(BLZ_EINVAL, "blz_comm_init_loopback: bad argument");
+	if (c->comm || c->loop)
+		return blz_fail(BLZ_EINVAL, "blz_comm_init_loopback: the context has a communicator already");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipEventCreateWithFlags(&c->loop_ready, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&c->loop_done, hipEventDisableTiming));
+	c->loop = g;
+	c->rank = rank;
+	const char *f = getenv("BLZ_FORCE_COMM");
+	c->force_comm = f && f[0] == '1';
+	return BLZ_OK;
 }

@@ -155,6 +155,11 @@ bool block_dot_mfma_supported(const KernelCfg &c);
 hipError_t launch_block_dot_mfma(const KernelCfg &c, const void *V, const void *AV, int64_t rows, u64 *partial, int max_blocks,
 				 int *nblocks, const DevCtl *ctl, hipStream_t s);
 
+/* dst[i] = sum over the nsrc buffers of src[q][i] (plain wrap-around sums of 8- or 4-byte words): the data movement of the
+ * loopback communicator's all-reduce / reduce-scatter (blz_api.hip) */
+#define BLZ_LOOP_MAX_RANKS 16
+hipError_t launch_sum_buffers(const void *const *src, int nsrc, void *dst, long long words, int word_bytes, hipStream_t s);
+
 /* flag |= any(X != 0) over `words` words */
 hipError_t launch_any_nonzero(const KernelCfg &c, const void *X, int64_t words, int *flag, hipStream_t s);
 

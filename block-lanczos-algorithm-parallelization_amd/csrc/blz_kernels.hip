@@ -2834,6 +2834,40 @@ hipError_t launch_reduce_modp(const KernelCfg &c, void *X, const void *S, int64_
 	return hipGetLastError();
 }
 
+struct SumSources {
+	const void *p[BLZ_LOOP_MAX_RANKS];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_sum_buffers(SumSources src, int nsrc, T *__restrict__ dst, long long words)
+{
+	const long long step = (long long)gridDim.x * BLOCK;
+	for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < words; i += step) {
+		T s = 0;
+		for (int q = 0; q < nsrc; q++)
+			s += ((const T *)src.p[q])[i];
+		dst[i] = s;
+	}
+}
+
+hipError_t launch_sum_buffers(const void *const *src, int nsrc, void *dst, long long words, int word_bytes, hipStream_t s)
+{
+	if (nsrc < 1 || nsrc > BLZ_LOOP_MAX_RANKS || words < 0)
+		return hipErrorInvalidValue;
+	if (words == 0)
+		return hipSuccess;
+	SumSources ss;
+	for (int q = 0; q < BLZ_LOOP_MAX_RANKS; q++)
+		ss.p[q] = q < nsrc ? src[q] : nullptr;
+	long long blocks = (words + BLOCK - 1) / BLOCK;
+	blocks = blocks > 2048 ? 2048 : blocks;
+	if (word_bytes == 8)
+		hipLaunchKernelGGL((k_sum_buffers<u64>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, ss, nsrc, (u64 *)dst, words);
+	else
+		hipLaunchKernelGGL((k_sum_buffers<u32>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, ss, nsrc, (u32 *)dst, words);
+	return hipGetLastError();
+}
+
 hipError_t launch_any_nonzero(const KernelCfg &c, const void *X, int64_t words, int *flag, hipStream_t s)
 {
 	if (words == 0)

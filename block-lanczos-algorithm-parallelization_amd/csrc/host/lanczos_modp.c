@@ -212,6 +212,7 @@ static struct {
 	blz_ctx *ctx[64];
 	const blz_prepared *P;
 	char uid[128];
+	blz_loop_group *loop;	/* BLZ_LOOPBACK=1: the G contexts share ONE device and meet in a loopback communicator (tests on a one-GPU box) */
 	int op, todo, block;
 	uint64_t *host, *host2;
 	int64_t its;
@@ -228,10 +229,11 @@ static void *team_worker(void *arg)
 	/* set-up in three phases with a join after each: a rank that fails in one of them (no memory on its device, say) is
 	 * reported before its peers enter the next, instead of leaving them inside ncclCommInitRank for ever */
 	case OP_CREATE:
-		rc = blz_create(&team.ctx[g], device + g, prime, (int)n);
+		rc = blz_create(&team.ctx[g], team.loop ? device : device + g, prime, (int)n);
 		break;
 	case OP_COMM:
-		rc = blz_comm_init(team.ctx[g], team.uid, sizeof team.uid, g, gpus);
+		rc = team.loop ? blz_comm_init_loopback(team.ctx[g], team.loop, g)
+			       : blz_comm_init(team.ctx[g], team.uid, sizeof team.uid, g, gpus);
 		break;
 	case OP_MATRIX:
 		rc = blz_set_matrix_prepared(team.ctx[g], team.P, g);
@@ -367,11 +369,20 @@ int main(int argc, char **argv)
 		(long)M.nnz);
 	fprintf(stderr, "  - Read in %.2fs\n", wtime() - t_load);
 
-	if (device < 0 || device + gpus > blz_device_count())
+	{
+		const char *lb = getenv("BLZ_LOOPBACK");
+		if (gpus > 1 && lb && lb[0] == '1') {
+			CHECK(blz_loop_group_create(gpus, &team.loop));
+			fprintf(stderr, "  - BLZ_LOOPBACK=1: %d ranks on GPU %d through the loopback communicator (a test mode, not a speed-up)\n", gpus,
+				device);
+		}
+	}
+	if (device < 0 || (team.loop ? device + 1 : device + gpus) > blz_device_count())
 		errx(1, "GPU %d..%d requested but %d HIP device(s) are visible", device, device + gpus - 1, blz_device_count());
 	team_run(OP_CREATE);
 	if (gpus > 1) {
-		CHECK(blz_comm_unique_id(team.uid, sizeof team.uid));
+		if (!team.loop)
+			CHECK(blz_comm_unique_id(team.uid, sizeof team.uid));
 		team_run(OP_COMM);
 	}
 	blz_ctx *ctx = team.ctx[0];
@@ -519,5 +530,7 @@ int main(int argc, char **argv)
 	free(v);
 	free(p);
 	team_run(OP_DESTROY);
+	if (team.loop)
+		blz_loop_group_destroy(team.loop);
 	exit(EXIT_SUCCESS);
 }

@@ -342,6 +342,20 @@ def checkpoint_load(path, prime, n, right, nrows):
     return int(its.value), v, p
 
 
+class LoopGroup:
+    """blz_loop_group: the loopback communicator of several contexts on one device (one thread per context)."""
+
+    def __init__(self, nranks):
+        self.h = C.c_void_p()
+        check(lib().blz_loop_group_create(C.c_int(nranks), C.byref(self.h)))
+        self.nranks = nranks
+
+    def close(self):
+        if self.h:
+            lib().blz_loop_group_destroy(self.h)
+            self.h = None
+
+
 class Context:
     """One GPU's solver state: the globals `n` and `prime` of the reference plus its four blocks."""
 
@@ -401,6 +415,9 @@ class Context:
         kind = C.c_int(0)
         check(lib().blz_locality(self.h, loc, C.byref(kind)))
         return (float(loc[0]), float(loc[1])), int(kind.value)
+
+    def comm_init_loopback(self, group, rank):
+        check(lib().blz_comm_init_loopback(self.h, group.h, C.c_int(rank)))
 
     def comm_info(self):
         """(ranks, rank) as the RCCL communicator reports them; (-1, -1) without one"""

@@ -365,6 +365,17 @@ int blz_comm_init(blz_ctx *ctx, const void *id, size_t id_bytes, int rank, int n
 int blz_comm_info(const blz_ctx *ctx, int *nranks_seen, int *rank_seen);
 /* pieces the exchange of product `transpose`'s operand (and the product itself) is cut into; 0 in the short-side form,
  * where nothing is gathered */
+/* Loopback communicator: the contexts of ONE process on ONE device, one host thread each, as the ranks of a job -- RCCL
+ * refuses two ranks on one GPU, and every other part of the multi-rank path (slabs, gathered layouts, the piece pipeline on
+ * two streams, the landing buffers of the collectives, what a batch does past the stop) is then the production code run
+ * with real multi-rank sums on a one-GPU box.  Create one group, attach every context (instead of blz_comm_init), drive
+ * each context from its own thread: the collectives inside blz_iterate / blz_final_check meet in the group (a rank that
+ * does not arrive within 120 s fails all of them with BLZ_ECOMM).  Not a transport: nothing leaves the device. */
+typedef struct blz_loop_group blz_loop_group;
+int blz_loop_group_create(int nranks, blz_loop_group **out);	/* at most 16 ranks */
+void blz_loop_group_destroy(blz_loop_group *g);			/* after every attached context has been destroyed */
+int blz_comm_init_loopback(blz_ctx *ctx, blz_loop_group *g, int rank);
+
 int blz_exchange_pieces(const blz_ctx *ctx, int transpose);
 /* the number of pieces this context would have a matrix of that shape prepared in for nranks ranks (what blz_prepare_for
  * passes to blz_prepare): for callers that prepare a rank's share themselves (blz_prepare_rank) */

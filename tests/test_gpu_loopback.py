@@ -1,0 +1,191 @@
+"""The multi-rank path of blz_iterate run with REAL multi-rank sums on ONE GPU (round 3).
+
+RCCL refuses two ranks on one device, and no multi-GPU box has been available to any round, so until now the exchange code had
+only ever run on a 1-rank communicator (where the sum of one residue is a residue and an all-gather is a copy) or as a Python
+restatement.  The loopback communicator (include/blz.h: blz_loop_group) stands in for RCCL only: the contexts of one process,
+one host thread each, meet in it; everything else -- rank-local slabs sized by their side, the gathered layouts, K pieces per
+exchange on the second stream with their events, the fused inner products on the last piece, the all-reduce into its own landing
+buffer, the short-side reduce-scatter, what a batch does past the stop -- is the code an 8-GPU job runs.  Checked against the
+oracle word for word (mpi/lanczos_modp.c:967-1149 and :1209-1247 are what this replaces in the reference).
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import blz
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+P61 = (1 << 61) - 1
+
+
+def run_ranks(nranks, fn):
+    """fn(rank) in one thread per rank; the first exception of any rank is re-raised"""
+    errs = [None] * nranks
+
+    def go(g):
+        try:
+            fn(g)
+        except BaseException as e:          # noqa: BLE001 (re-raised below)
+            errs[g] = e
+
+    ths = [threading.Thread(target=go, args=(g,)) for g in range(nranks)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(600)
+    for e in errs:
+        if e is not None:
+            raise e
+
+
+def loopback_solve(M, p, n, right, nranks, batch=16, extra=0, stop_after=-1):
+    """every rank: context, loopback communicator, its slabs, blz_iterate in batches until the (replicated) stop; returns what
+    the ranks hold"""
+    group = blz.LoopGroup(nranks)
+    out = [None] * nranks
+
+    def rank_main(g):
+        with blz.Context(p, n) as ctx:
+            ctx.comm_init_loopback(group, g)
+            assert ctx.comm_info() == (nranks, g)
+            ctx.set_matrix(M, right, g, nranks)
+            ctx.init_v()
+            stopped = False
+            while not stopped:
+                todo = batch if stop_after < 0 else min(batch, stop_after - ctx.iterations)
+                if todo <= 0:
+                    break
+                stopped = ctx.iterate(todo)[1]
+            if extra:
+                assert ctx.iterate(extra)[:2] == (0, True)           # a whole batch past the stop
+            out[g] = dict(v=ctx.get_block(blz.V), p=ctx.get_block(blz.P), tmp=ctx.get_block(blz.TMP), its=ctx.iterations,
+                          vtav=ctx.get_small(blz.VTAV), vtaav=ctx.get_small(blz.VTAAV), winv=ctx.get_small(blz.WINV),
+                          check=ctx.final_check() if stop_after < 0 else None,
+                          pieces=(ctx.exchange_pieces(False), ctx.exchange_pieces(True)),
+                          short=(ctx.short_side(False), ctx.short_side(True)))
+
+    try:
+        run_ranks(nranks, rank_main)
+    finally:
+        group.close()
+    return out
+
+
+def together(parts, key):
+    full = np.zeros_like(parts[0][key])
+    for q in parts:                      # a rank returns its own rows, zeros elsewhere
+        full |= q[key]
+    return full
+
+
+@pytest.mark.parametrize("nranks,chunks", [(2, None), (3, "1"), (8, None), (2, "4"), (3, "3")])
+@pytest.mark.parametrize("name,p,n,right", [("rand3000x2000", P61, 8, False), ("rand300x200", 65537, 4, True),
+                                            ("wide120x260", 2147483647, 4, True), ("rand3000x2000", 2305843009213693907, 16, False)])
+def test_whole_solve_with_loopback_ranks(monkeypatch, name, p, n, right, nranks, chunks):
+    """blz_iterate on 2 / 3 / 8 ranks to termination and a batch beyond: v, p, tmp word for word the oracle's, the n x n operands
+    residues and identical on every rank (they are all-reduced sums of the ranks' residues), the final check the reference's."""
+    if chunks:
+        monkeypatch.setenv("BLZ_AG_CHUNKS", chunks)
+    path = os.path.join(GOLDEN, name + ".mtx")
+    M, Mo = blz.Matrix.load(path, p), orc.Matrix.load(path, p)
+    want = orc.block_lanczos(Mo, n, p, right=right)
+    got = loopback_solve(M, p, n, right, nranks, batch=13, extra=29)
+    assert all(q["its"] == want["iterations"] for q in got)
+    assert np.array_equal(together(got, "v"), want["v"]) and np.array_equal(together(got, "p"), want["p"])
+    assert np.array_equal(together(got, "tmp"), want["tmp"])
+    for q in got:
+        assert (q["vtav"] < p).all() and (q["vtaav"] < p).all() and (q["winv"] < p).all()
+        assert np.array_equal(q["vtav"], got[0]["vtav"]) and np.array_equal(q["winv"], got[0]["winv"])
+        assert q["check"] == (bool(want["v"].any()), not want["tmp"].any())
+    if chunks:
+        assert got[0]["pieces"] == (int(chunks), int(chunks))
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+@pytest.mark.parametrize("shape,right,forced", [((9000, 400), False, None), ((400, 9000), True, None), ((2500, 1800), False, "1")])
+def test_short_side_exchange_with_loopback_ranks(monkeypatch, shape, right, nranks, forced):
+    """Tall / wide matrices: the product over the long side runs in its short-side form -- every rank multiplies its own slab, the
+    full-length partial products are REDUCE-SCATTERED (real sums of up to 8 ranks' residues, < 8 p < 2^64) into a landing buffer
+    and brought back to residues -- whole solve plus a batch past the stop, against the oracle."""
+    if forced:
+        monkeypatch.setenv("BLZ_SHORT_SIDE", forced)
+    p, n = P61, 8
+    M = blz.Matrix.synth(shape[0], shape[1], 10 * max(shape), 0x4C4F4F50, p)
+    Mo = orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+    want = orc.block_lanczos(Mo, n, p, right=right)
+    got = loopback_solve(M, p, n, right, nranks, batch=32, extra=40)
+    assert got[0]["short"].count(True) == (2 if forced else 1)
+    assert all(q["its"] == want["iterations"] for q in got)
+    assert np.array_equal(together(got, "v"), want["v"]) and np.array_equal(together(got, "p"), want["p"])
+    tmp = together(got, "tmp")
+    assert (tmp < p).all() and np.array_equal(tmp, want["tmp"])
+    for q in got:
+        assert (q["vtav"] < p).all() and (q["vtaav"] < p).all()
+        assert q["check"] == (bool(want["v"].any()), not want["tmp"].any())
+
+
+def test_trajectory_with_loopback_ranks_at_config_shaped_sizes():
+    """A GL7d19-like shape scaled down (200 k x 205 k, 4 M entries, n = 8, p = 2^61-1) on 4 ranks, 12 iterations: large enough
+    for several pieces per exchange by the plan's own choice and for every kernel's multi-workgroup form."""
+    p, n = P61, 8
+    M = blz.Matrix.synth(200000, 205000, 4000000, 0x474C3764, p)
+    Mo = orc.Matrix(M.nrows, M.ncols, M.i, M.j, M.x)
+    want = orc.block_lanczos(Mo, n, p, stop_after=12)
+    got = loopback_solve(M, p, n, False, 4, batch=5, stop_after=12)
+    assert all(q["its"] == 12 for q in got)
+    assert np.array_equal(together(got, "v"), want["v"]) and np.array_equal(together(got, "p"), want["p"])
+
+
+def test_a_rank_that_never_arrives_fails_the_others_instead_of_hanging():
+    """Only rank 0 of a 2-rank group iterates: its first collective must come back with BLZ_ECOMM (after the group's time-out,
+    shortened here), not hang the suite."""
+    p, n = P61, 4
+    M = blz.Matrix.load(os.path.join(GOLDEN, "rand300x200.mtx"), p)
+    os.environ["BLZ_LOOP_TIMEOUT_S"] = "3"
+    group = blz.LoopGroup(2)
+    try:
+        with blz.Context(p, n) as ctx:
+            ctx.comm_init_loopback(group, 0)
+            ctx.set_matrix(M, False, 0, 2)
+            ctx.init_v()
+            with pytest.raises(blz.BlzError) as e:
+                ctx.iterate(1)
+            assert e.value.code == blz.ECOMM
+    finally:
+        del os.environ["BLZ_LOOP_TIMEOUT_S"]
+        group.close()
+
+
+@pytest.mark.parametrize("gpus", [2, 3, 8])
+def test_cli_with_several_contexts_on_one_gpu_reproduces_the_reference_hashes(tmp_path, gpus):
+    """lib/lanczos_modp --gpus G with BLZ_LOOPBACK=1: the G contexts of the process share this box's one GPU and meet in the
+    loopback communicator; the host side is what a G-GPU run executes (one thread per context and operation, the prepared
+    matrix cut G ways, the output assembled from G slabs, checkpoints collected from G contexts).  The output file must be the one
+    the unmodified reference binary wrote (tests/golden/cli.json)."""
+    import hashlib
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "block-lanczos-algorithm-parallelization_amd", "lib", "lanczos_modp")
+    cli = json.load(open(os.path.join(GOLDEN, "cli.json")))
+    cli.pop("_validation")
+    ran = 0
+    for tag, c in cli.items():
+        if c["matrix"] not in ("rand300x200", "wide120x260"):
+            continue
+        out = str(tmp_path / f"{tag}_g{gpus}.mtx")
+        r = subprocess.run([exe, "--matrix", os.path.join(GOLDEN, c["matrix"] + ".mtx"), "--prime", str(c["prime"]),
+                            "--n", str(c["n"]), "--output-file", out, "--gpus", str(gpus), "--checkpoint", "0"]
+                           + (["--right"] if c["right"] else []), capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, BLZ_LOOPBACK="1"), cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert "loopback communicator" in r.stderr
+        assert f"after {c['iterations']} iterations" in r.stdout, (tag, r.stdout[-400:])
+        assert hashlib.sha256(open(out, "rb").read()).hexdigest() == c["out_sha256"], tag
+        ran += 1
+    assert ran >= 2
