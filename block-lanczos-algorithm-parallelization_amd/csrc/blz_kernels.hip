@@ -1333,7 +1333,7 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, bool al
 		 * product: 535 us as k_spmv, 332 us staged (profiles/r03_exp_band_staged_always.txt; round 2 saw 516 -> 369 on the
 		 * GL7d19 shape with all entries in a band) -- except on heavy-tailed row lengths, where it loses (`nfs` workload: 853
 		 * against 664 us).  The product that carries the inner products gains nothing from it (406 against 404 us). */
-		const bool local = allow_dyn && D.locality < 0.3 && !D.uneven;
+		const bool local = allow_dyn && D.locality < 0.3 && !D.uneven && D.outlier_share < 0.02;	/* (nfs: 17 % of the entries in outlier rows) */
 		if (!(e && e[0] == '1') && a >= 12.0 && a < 32.0 && !local)
 			return;
 	}

@@ -11,5 +11,5 @@ for w in gl7d19 relat9 relat8 synth5q; do
 done
 tools/gpu_pmc_extra.sh pmc_synth5q --workload synth5q --steps 3 --warmup 1 > gpurun_out/pmc_synth5q.log 2>&1 || { echo "pmc synth5q failed"; tail -5 gpurun_out/pmc_synth5q.log; exit 1; }
 echo "== pmc synth5q done"
-timeout -k 10 400 python bench.py > gpurun_out/bench_default_r02.json 2> gpurun_out/bench_default_r02.err || { echo "default bench failed"; tail -5 gpurun_out/bench_default_r02.err; exit 1; }
+timeout -k 10 600 python bench.py > gpurun_out/bench_default_r03.json 2> gpurun_out/bench_default_r03.err || { echo "default bench failed"; tail -5 gpurun_out/bench_default_r03.err; exit 1; }
 echo "== default bench done"
