@@ -119,6 +119,7 @@ def self_launch(args):
         print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "cmd": cmd}))
         return 0
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))    # (the launcher would set 1)
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT, text=True)
     line = None
     for ln in child.stdout:                 # rank 0 writes exactly one line that starts with '{'; anything else is noise
@@ -314,14 +315,21 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer exchange between the ranks fails with
+    # "hipIpcGetMemHandle: invalid argument"; it must be in the environment before the first HIP call of the process
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:          # a launcher's WORLD_SIZE wins over the flag
         args.gpus = world
 
-    if world > 1 and "OMP_NUM_THREADS" not in os.environ:
-        # the host-side set-up (generation, renumbering, CSR builds) is OpenMP code: share the cores between the ranks
+    if world > 1 and ("OMP_NUM_THREADS" not in os.environ or
+                      (os.environ["OMP_NUM_THREADS"] == "1" and "TORCHELASTIC_RUN_ID" in os.environ
+                       and os.environ.get("BLZ_BENCH_KEEP_OMP") != "1")):
+        # the host-side set-up (generation, renumbering, CSR builds) is OpenMP code: share the cores between the ranks.
+        # torch.distributed.run sets OMP_NUM_THREADS=1 for its workers when the caller has not set it -- that would make rank 0
+        # prepare the matrix on one core; the OpenMP runtime has not been loaded yet at this point, so this still takes effect.
         os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))
 
     import numpy as np

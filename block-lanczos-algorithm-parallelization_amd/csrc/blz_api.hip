@@ -179,6 +179,7 @@ struct blz_ctx {
 	DevCtl *ctl_pinned = nullptr, *ctl_pinned_dev = nullptr;	/* host-mapped landing place of the control words */
 	ncclComm_t comm = nullptr;
 	blz_loop_group *loop = nullptr;		/* loopback communicator instead of RCCL (contexts of one process on one device) */
+	int loop_rank = -1;			/* this context's rank in it (the matrix must be set with the same rank and rank count) */
 	hipEvent_t loop_ready = nullptr, loop_done = nullptr;
 	/* perm[side][original row] = row in the solver's numbering (empty = identity); inv is the inverse */
 	std::vector<int32_t> perm[2], inv[2];
@@ -639,6 +640,9 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 		return blz_fail(BLZ_EINVAL, "nranks * p must not exceed 2**64 (u64 all-reduce of residues)");
 	if (K > 1 && nranks == 1 && !c->force_comm)
 		return blz_fail(BLZ_EINVAL, "blz_set_matrix_prepared: the matrix was prepared in %d pieces for a single rank", K);
+	if (c->loop && (rank != c->loop_rank || nranks != c->loop->nranks))
+		return blz_fail(BLZ_EINVAL, "blz_set_matrix_prepared: rank %d of %d, but the context is rank %d of %d in its loopback communicator",
+				rank, nranks, c->loop_rank, c->loop->nranks);
 	HIPCHK(hipSetDevice(c->device));
 	if (c->iter_graph) {
 		hipGraphExecDestroy(c->iter_graph);
@@ -1141,7 +1145,7 @@ enum { LOOP_GATHER = 0, LOOP_SUM64 = 1, LOOP_SUM64_SEGMENT = 2, LOOP_SUM32 = 3 }
 static int loop_collective(blz_ctx *c, int kind, const void *send, void *recv, size_t count, hipStream_t st)
 {
 	blz_loop_group *g = c->loop;
-	const int r = c->rank, N = g->nranks;
+	const int r = c->loop_rank, N = g->nranks;
 	g->send[(size_t)r] = send;
 	HIPCHK(hipEventRecord(c->loop_ready, st));
 	g->ready[(size_t)r] = c->loop_ready;
@@ -1729,7 +1733,7 @@ extern "C" int blz_comm_info(const blz_ctx *c, int *nranks_seen, int *rank_seen)
 	int cnt = -1, rk = -1;
 	if (c->loop) {
 		cnt = c->loop->nranks;
-		rk = c->rank;
+		rk = c->loop_rank;
 	} else if (c->comm) {
 		NCCLCHK(g_rccl.CommCount(c->comm, &cnt));
 		NCCLCHK(g_rccl.CommUserRank(c->comm, &rk));
@@ -1789,6 +1793,7 @@ extern "C" int blz_comm_init_loopback(blz_ctx *c, blz_loop_group *g, int rank)
 	HIPCHK(hipEventCreateWithFlags(&c->loop_ready, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&c->loop_done, hipEventDisableTiming));
 	c->loop = g;
+	c->loop_rank = rank;
 	c->rank = rank;
 	const char *f = getenv("BLZ_FORCE_COMM");
 	c->force_comm = f && f[0] == '1';

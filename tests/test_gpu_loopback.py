@@ -142,6 +142,23 @@ def test_trajectory_with_loopback_ranks_at_config_shaped_sizes():
     assert np.array_equal(together(got, "v"), want["v"]) and np.array_equal(together(got, "p"), want["p"])
 
 
+def test_the_matrix_must_be_set_with_the_rank_the_communicator_knows():
+    p, n = P61, 4
+    M = blz.Matrix.load(os.path.join(GOLDEN, "rand300x200.mtx"), p)
+    group = blz.LoopGroup(3)
+    try:
+        with blz.Context(p, n) as ctx:
+            ctx.comm_init_loopback(group, 1)
+            for rank, nranks in ((0, 3), (1, 2), (2, 3)):
+                with pytest.raises(blz.BlzError):
+                    ctx.set_matrix(M, False, rank, nranks)
+            ctx.set_matrix(M, False, 1, 3)
+            with pytest.raises(blz.BlzError):
+                ctx.comm_init_loopback(group, 2)          # one communicator per context
+    finally:
+        group.close()
+
+
 def test_a_rank_that_never_arrives_fails_the_others_instead_of_hanging():
     """Only rank 0 of a 2-rank group iterates: its first collective must come back with BLZ_ECOMM (after the group's time-out,
     shortened here), not hang the suite."""
