@@ -1368,7 +1368,36 @@ int blz_shard_matrix(const blz_coo *M, int right, int rank, int nranks, int chun
  * and the two CSR builds (GL7d19 shape ~1 s, config 5 ~48 s per rank).  A loaded cache is mmapped: N processes on one
  * node share its pages.
  */
-#define PREP_MAGIC "BLZPREP2"
+#define PREP_MAGIC "BLZPREP3"
+
+/* FNV-1a over 8-byte words, 1 MB pieces hashed in parallel and chained (the file hash of the CLI's cache key, and the
+ * payload checksum of the cache itself) */
+static uint64_t hash_bytes(const unsigned char *m, size_t len)
+{
+	const size_t piece = 1u << 20, np = (len + piece - 1) / piece;
+	uint64_t *hp = malloc(sizeof *hp * (np ? np : 1));
+	uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)len;
+	if (!hp)
+		return 0;
+#pragma omp parallel for schedule(static)
+	for (int64_t q = 0; q < (int64_t)np; q++) {
+		const size_t lo = (size_t)q * piece, hi = lo + piece < len ? lo + piece : len;
+		uint64_t x = 0xcbf29ce484222325ull;
+		size_t k = lo;
+		for (; k + 8 <= hi; k += 8) {
+			uint64_t wd;
+			memcpy(&wd, m + k, 8);
+			x = (x ^ wd) * 0x100000001b3ull;
+		}
+		for (; k < hi; k++)
+			x = (x ^ m[k]) * 0x100000001b3ull;
+		hp[q] = x;
+	}
+	for (size_t q = 0; q < np; q++)
+		h = (h ^ hp[q]) * 0x100000001b3ull;
+	free(hp);
+	return h ? h : 1;
+}
 
 typedef struct {
 	char magic[8];
@@ -1379,6 +1408,7 @@ typedef struct {
 	double share[2], locality[2];
 	uint64_t off_perm[2], off_bounds[2], off_rp[2], off_ci[2], off_va[2];
 	uint64_t total;
+	uint64_t payload_hash;		/* hash_bytes of everything behind the header (bit rot, a torn or foreign file) */
 } prep_header;
 
 void blz_prepared_free(blz_prepared *P)
@@ -1708,7 +1738,6 @@ int blz_prepared_save(const blz_prepared *P, const char *path, uint64_t key)
 		unlink(tmp);
 		return blz_fail(BLZ_EIO, "cannot map %s: %s", tmp, strerror(errno));
 	}
-	memcpy(m, &h, sizeof h);
 	for (int q = 0; q < 2; q++) {
 		if (P->has_perm)
 			memcpy(m + h.off_perm[q], P->perm[q], sizeof(int32_t) * (size_t)plen[q]);
@@ -1718,6 +1747,8 @@ int blz_prepared_save(const blz_prepared *P, const char *path, uint64_t key)
 		if (h.has_val[q])
 			memcpy(m + h.off_va[q], P->full[q].val, sizeof(uint32_t) * (size_t)P->full[q].nnz);
 	}
+	h.payload_hash = hash_bytes((const unsigned char *)m + up64(sizeof h), (size_t)(h.total - up64(sizeof h)));
+	memcpy(m, &h, sizeof h);
 	const int bad = msync(m, h.total, MS_SYNC) != 0;
 	munmap(m, h.total);
 	if (bad || rename(tmp, path) != 0) {	/* atomic: a reader sees the old cache or the whole new one */
@@ -1749,6 +1780,11 @@ int blz_prepared_load(const char *path, uint64_t key, blz_prepared **out)
 	if (memcmp(h.magic, PREP_MAGIC, 8) != 0 || h.total != (uint64_t)st.st_size || h.key != key || h.nranks < 1) {
 		munmap(m, (size_t)st.st_size);
 		return blz_fail(BLZ_EFORMAT, "%s: not a cache of this matrix / prime / width / rank count (or an older format)", path);
+	}
+	if ((uint64_t)st.st_size < up64(sizeof h) ||
+	    hash_bytes((const unsigned char *)m + up64(sizeof h), (size_t)st.st_size - up64(sizeof h)) != h.payload_hash) {
+		munmap(m, (size_t)st.st_size);
+		return blz_fail(BLZ_EFORMAT, "%s: damaged cache (checksum)", path);
 	}
 	blz_prepared *P = calloc(1, sizeof *P);
 	if (!P) {
@@ -1864,28 +1900,7 @@ uint64_t blz_file_hash(const char *path)
 	close(fd);
 	if (m == MAP_FAILED)
 		return 0;
-	const size_t piece = 1u << 20, np = (len + piece - 1) / piece;
-	uint64_t *hp = malloc(sizeof *hp * np);
-	uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)len;
-	if (hp) {
-#pragma omp parallel for schedule(static)
-		for (int64_t q = 0; q < (int64_t)np; q++) {
-			const size_t lo = (size_t)q * piece, hi = lo + piece < len ? lo + piece : len;
-			uint64_t x = 0xcbf29ce484222325ull;
-			size_t k = lo;
-			for (; k + 8 <= hi; k += 8) {
-				uint64_t wd;
-				memcpy(&wd, m + k, 8);
-				x = (x ^ wd) * 0x100000001b3ull;
-			}
-			for (; k < hi; k++)
-				x = (x ^ m[k]) * 0x100000001b3ull;
-			hp[q] = x;
-		}
-		for (size_t q = 0; q < np; q++)
-			h = (h ^ hp[q]) * 0x100000001b3ull;
-		free(hp);
-	}
+	const uint64_t h = hash_bytes(m, len);
 	munmap((void *)m, len);
 	return h ? h : 1;
 }
