@@ -62,6 +62,11 @@ WORKLOADS = {
     "nfs": dict(desc="EXTRA (not a BASELINE config): structured synthetic, 40 % of a row's entries ~1/(c+16), 30 % in a band "
                      "of 4096 columns, 30 % uniform", rows=2000000, cols=2000000, nnz=40000000, prime=P61, n=8, right=False,
                 seed=0x4E465331, pattern=False, structured=dict(hot_pct=40, band_pct=30, band=4096)),
+    # EXTRA, never the headline: every entry in a band of 4096 columns around r*C/R -- all gathers hit L1 / L2, so the products are
+    # paced by the kernels themselves, not by the fabric (what a well-ordered real matrix would look like at best)
+    "band": dict(desc="EXTRA (not a BASELINE config): banded synthetic, every entry within 2048 columns of r*C/R", rows=2000000,
+                 cols=2000000, nnz=40000000, prime=P61, n=8, right=False, seed=0x42414E44, pattern=False,
+                 structured=dict(hot_pct=0, band_pct=100, band=4096)),
     "tiny": dict(desc="tiny synthetic (self-test)", rows=20000, cols=15000, nnz=200000, prime=P61,
                  n=8, right=False, seed=0x54494E59, pattern=False),
     "tiny5": dict(desc="tiny config-5-like synthetic (self-test of the per-rank set-up)", rows=60000, cols=60000, nnz=1800000, prime=P61,

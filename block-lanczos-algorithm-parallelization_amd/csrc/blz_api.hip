@@ -186,6 +186,7 @@ struct blz_ctx {
 	bool reorder = true;		/* BLZ_NO_REORDER=1 keeps the file's numbering */
 	bool pack = true;		/* BLZ_NO_PACK=1 keeps col_idx and val as two arrays */
 	bool fuse_dot = true;		/* BLZ_NO_FUSE=1 keeps block_dot as its own kernel (A/B measurements) */
+	bool fuse_local_off = false;	/* this matrix: the second product runs the staged form and block_dot its own kernel (gathers that hit) */
 	int un = 0;			/* the caller's block width; cfg.n is the width in HBM (below) */
 	bool use_graph = false;		/* BLZ_GRAPH=1: single-GPU iterations are replayed from a captured hipGraph */
 	hipGraphExec_t iter_graph = nullptr;
@@ -651,6 +652,7 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 	c->right = right;
 	c->rank = rank;
 	c->nranks = nranks;
+	c->fuse_local_off = false;
 	/* side 0 = rows of v: rows of M for a left kernel, columns of M for a right kernel
 	 * (sequential/lanczos_modp.c:592-593). */
 	c->glob_rows[0] = right ? P->ncols : P->nrows;
@@ -724,6 +726,19 @@ extern "C" int blz_set_matrix_prepared(blz_ctx *c, const blz_prepared *P, int ra
 			/* product t gathers block rows by the column index of its slab: columns of M for t = 0, rows of M for t = 1 */
 			const int64_t hot_t = c->cfg.panel ? P->hot[t == 0 ? 1 : 0] : 0;
 			rc = upload_csr(c, slab, c->csr[t][0], hot_t, dot_slab, nranks == 1 ? c->locality[t] : 1.0);
+			{
+				/* Gathers that mostly hit (a banded / well-ordered matrix: the locality rule of spmv_plan_staged): the product
+				 * is paced by the kernel, and there the staged form with 16-byte lanes plus the inner products as their own
+				 * matrix-core kernel beat the fused lane-per-column form -- band matrix, 2 M x 2 M, n = 8: 308 + 55 us against
+				 * 389 (profiles/r03_band_switches.txt).  Where the fabric paces the gathers the fused form stays (the inner
+				 * products ride along for 20 us). */
+				DevCsr &D = c->csr[t][0];
+				if (rc == BLZ_OK && dot_slab && nranks == 1 && block_dot_mfma_supported(c->cfg) && D.panel_rows == 0 &&
+				    D.locality < 0.3 && !D.uneven && D.outlier_share < 0.02) {
+					spmv_plan_staged(c->cfg, slab.row_ptr, D, true);
+					c->fuse_local_off = D.st_ok;
+				}
+			}
 			const char *xe = getenv("BLZ_XCD_RANGES");	/* 0 / 1 force it off / on (A/B) */
 			/* (an operand of a few MB sits in every L2 anyway: nothing to separate) */
 			const bool big = (double)slab.cols * c->cfg.n * c->cfg.word > 8e6;
@@ -1414,7 +1429,7 @@ static int enqueue_iteration(blz_ctx *c)
 {
 	int rc;
 	if ((rc = enqueue_product(c, !c->right, BLZ_V, BLZ_TMP, false, nullptr)) != BLZ_OK) return rc;	/* :635 */
-	if (c->fuse_dot && spmv_dot_supported(c->cfg) && c->count[0] > 0 && !c->short_side[c->right]) {
+	if (c->fuse_dot && !c->fuse_local_off && spmv_dot_supported(c->cfg) && c->count[0] > 0 && !c->short_side[c->right]) {
 		int nb = 0;							/* :636 + :640 in one kernel */
 		if ((rc = enqueue_product(c, c->right, BLZ_TMP, BLZ_AV, true, &nb)) != BLZ_OK) return rc;
 		{
