@@ -1313,8 +1313,15 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, bool al
 		G <<= 1;
 	if (spmv_split_log2(c, D.rows, D.nnz) != 0)	/* few long rows shared by adjacent groups: k_spmv */
 		return;
-	/* lanes per row: G, or 8 lanes of two words at n = 16 (8 rows per wavefront); the heuristics below go by the row width G */
-	const bool pair = spmv_pair_lanes(c) && allow_dyn && c.stage_dyn != 1;	/* (a slab that carries the inner products keeps one word per lane) */
+	const double avg = D.kept_mean >= 0.0 ? D.kept_mean : (double)D.nnz / (double)D.rows;
+	/* gathers that mostly hit (see below) */
+	const bool local = allow_dyn && D.locality < 0.3 && !D.uneven && D.outlier_share < 0.02;	/* (nfs: 17 % of the entries in outlier rows) */
+	/* lanes per row: G, or G / 2 lanes of two words (16-byte gathers and stores); the heuristics below go by the row width G.
+	 * A slab that carries the inner products keeps one word per lane.  At n = 8 the form pays on rows of a few entries (the
+	 * output rows are then a large part of the traffic: relat9 shape from the right, rows of 3: 622 -> 616 us) and on
+	 * gathers that hit (band matrix: 411 -> 326 us), and LOSES on long rows gathered from a large operand (relat9 shape from
+	 * the left, rows of 71 out of 791 MB: 735 -> 780 us): profiles/r03_exp_pair_rows.txt */
+	const bool pair = spmv_pair_lanes(c) && allow_dyn && c.stage_dyn != 1 && (G == 16 || avg < 12.0 || local);
 	D.st_pair = pair;
 	{
 		/* Measured on MI355X (gpurun_out r2a..r2g, profiles/r02_staged_*): staging pays where the stream is a large
@@ -1333,12 +1340,10 @@ void spmv_plan_staged(const KernelCfg &c, const u32 *row_ptr, DevCsr &D, bool al
 		 * product: 535 us as k_spmv, 332 us staged (profiles/r03_exp_band_staged_always.txt; round 2 saw 516 -> 369 on the
 		 * GL7d19 shape with all entries in a band) -- except on heavy-tailed row lengths, where it loses (`nfs` workload: 853
 		 * against 664 us).  The product that carries the inner products gains nothing from it (406 against 404 us). */
-		const bool local = allow_dyn && D.locality < 0.3 && !D.uneven && D.outlier_share < 0.02;	/* (nfs: 17 % of the entries in outlier rows) */
 		if (!(e && e[0] == '1') && a >= 12.0 && a < 32.0 && !local)
 			return;
 	}
 	const int GPW = pair ? 128 / G : 64 / G, NS = (D.val && !D.palette) ? 2 : 1;
-	const double avg = D.kept_mean >= 0.0 ? D.kept_mean : (double)D.nnz / (double)D.rows;
 	/* Rows of a few entries (relat9 shape, 3.15 per row, profiles/r02_exp_staged_sweep_relat9.txt): a batch of 8 gathers
 	 * per lane is mostly switched-off slots, and 16 wavefronts per CU with the larger window beat 32 with the smaller one
 	 * (672 -> 622 us in the iteration; 4 per CU x U = 4: 623 us, 8 x 4: 691, 4 x 8: 772, 8 x 8: 739 in the sweep). */
