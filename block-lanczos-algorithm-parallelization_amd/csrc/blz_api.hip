@@ -116,6 +116,8 @@ struct blz_loop_group {
 	bool broken = false;
 	int timeout_s = 120;		/* BLZ_LOOP_TIMEOUT_S at creation (tests of the time-out itself) */
 	std::vector<const void *> send;
+	/* one pair of events per rank, OWNED BY THE GROUP and destroyed with it: a rank that is done may destroy its context
+	 * while a peer's stream still holds a wait on its event that has not executed yet */
 	std::vector<hipEvent_t> ready, done;
 	/* all ranks meet; false after the time-out or once any rank has given up */
 	bool meet()
@@ -180,7 +182,6 @@ struct blz_ctx {
 	ncclComm_t comm = nullptr;
 	blz_loop_group *loop = nullptr;		/* loopback communicator instead of RCCL (contexts of one process on one device) */
 	int loop_rank = -1;			/* this context's rank in it (the matrix must be set with the same rank and rank count) */
-	hipEvent_t loop_ready = nullptr, loop_done = nullptr;
 	/* perm[side][original row] = row in the solver's numbering (empty = identity); inv is the inverse */
 	std::vector<int32_t> perm[2], inv[2];
 	bool reorder = true;		/* BLZ_NO_REORDER=1 keeps the file's numbering */
@@ -405,8 +406,6 @@ extern "C" void blz_destroy(blz_ctx *c)
 		hipGraphExecDestroy(c->iter_graph);
 	if (c->comm && g_rccl.CommDestroy)
 		g_rccl.CommDestroy(c->comm);
-	if (c->loop_ready) hipEventDestroy(c->loop_ready);
-	if (c->loop_done) hipEventDestroy(c->loop_done);
 	for (int t = 0; t < 2; t++)
 		for (auto &A : c->csr[t])
 			free_csr(A);
@@ -1162,9 +1161,7 @@ static int loop_collective(blz_ctx *c, int kind, const void *send, void *recv, s
 	blz_loop_group *g = c->loop;
 	const int r = c->loop_rank, N = g->nranks;
 	g->send[(size_t)r] = send;
-	HIPCHK(hipEventRecord(c->loop_ready, st));
-	g->ready[(size_t)r] = c->loop_ready;
-	g->done[(size_t)r] = c->loop_done;
+	HIPCHK(hipEventRecord(g->ready[(size_t)r], st));
 	if (!g->meet())
 		return blz_fail(BLZ_ECOMM, "loopback communicator: a rank did not arrive (or gave up)");
 	for (int q = 0; q < N; q++)
@@ -1179,7 +1176,7 @@ static int loop_collective(blz_ctx *c, int kind, const void *send, void *recv, s
 			src[q] = kind == LOOP_SUM64_SEGMENT ? (const void *)((const u64 *)g->send[(size_t)q] + (size_t)r * count) : g->send[(size_t)q];
 		HIPCHK(launch_sum_buffers(src, N, recv, (long long)count, kind == LOOP_SUM32 ? 4 : 8, st));
 	}
-	HIPCHK(hipEventRecord(c->loop_done, st));
+	HIPCHK(hipEventRecord(g->done[(size_t)r], st));
 	if (!g->meet())
 		return blz_fail(BLZ_ECOMM, "loopback communicator: a rank did not arrive (or gave up)");
 	for (int q = 0; q < N; q++)
@@ -1795,6 +1792,13 @@ extern "C" int blz_loop_group_create(int nranks, blz_loop_group **out)
 
 extern "C" void blz_loop_group_destroy(blz_loop_group *g)
 {
+	if (!g)
+		return;
+	(void)hipDeviceSynchronize();
+	for (hipEvent_t e : g->ready)
+		if (e) hipEventDestroy(e);
+	for (hipEvent_t e : g->done)
+		if (e) hipEventDestroy(e);
 	delete g;
 }
 
@@ -1805,8 +1809,13 @@ extern "C" int blz_comm_init_loopback(blz_ctx *c, blz_loop_group *g, int rank)
 	if (c->comm || c->loop)
 		return blz_fail(BLZ_EINVAL, "blz_comm_init_loopback: the context has a communicator already");
 	HIPCHK(hipSetDevice(c->device));
-	HIPCHK(hipEventCreateWithFlags(&c->loop_ready, hipEventDisableTiming));
-	HIPCHK(hipEventCreateWithFlags(&c->loop_done, hipEventDisableTiming));
+	{
+		std::lock_guard<std::mutex> lk(g->mu);
+		if (g->ready[(size_t)rank])
+			return blz_fail(BLZ_EINVAL, "blz_comm_init_loopback: rank %d of the group is taken", rank);
+		HIPCHK(hipEventCreateWithFlags(&g->ready[(size_t)rank], hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&g->done[(size_t)rank], hipEventDisableTiming));
+	}
 	c->loop = g;
 	c->loop_rank = rank;
 	c->rank = rank;
