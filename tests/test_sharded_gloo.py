@@ -5,6 +5,9 @@ What this pins: the nnz-balanced partition, the slab extraction, the column rema
 equal-count all-gather of padded slabs, the u64-sum-then-mod all-reduce of the n x n products, and the replicated
 semi_inverse decision.  What it cannot pin (no GPU here, and RCCL refuses two ranks on one GPU): the RCCL calls
 themselves -- those are exercised with BLZ_FORCE_COMM=1 on one rank in test_gpu_sharded.py.
+
+(Round 3: the library's own multi-rank path -- blz_iterate with 2, 3 and 8 ranks, real sums -- is held to the oracle on one GPU by
+tests/test_gpu_loopback.py; this file keeps checking the partition / remap / piece layout against the schedule on CPU ranks.)
 """
 import os
 import socket
