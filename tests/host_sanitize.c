@@ -63,7 +63,7 @@ static void matrix_round(const blz_coo *M, uint64_t prime, const char *scratch)
 		REQUIRE(hot[0] <= 7 && hot[1] <= 300);
 		hot[0] = 5;
 		hot[1] = 64;
-		REQUIRE(blz_reorder_auto(M, r2, c2, hot, 0.01, share, 2, loc, &kind) == BLZ_OK && kind >= 0 && kind <= 2);
+		REQUIRE(blz_reorder_auto(M, r2, c2, hot, 0.01, share, 2, loc, &kind) == BLZ_OK && kind >= 0 && kind <= 3);
 		for (int64_t r = 0; r < M->nrows; r++)
 			REQUIRE(r2[r] >= 0 && r2[r] < M->nrows);
 		free(r2);
@@ -105,6 +105,26 @@ static void matrix_round(const blz_coo *M, uint64_t prime, const char *scratch)
 				}
 			blz_prepared_free(Q);
 			blz_prepared_free(P);
+			/* damaged caches (round 3): a flipped word behind the header (checksum), a header whose offsets point past the
+			 * file, a truncated file: refused, nothing read out of bounds */
+			{
+				FILE *fd = fopen(cpath, "r+");
+				REQUIRE(fd != NULL);
+				REQUIRE(fseek(fd, 0, SEEK_END) == 0);
+				const long len = ftell(fd);
+				uint32_t junk = 0x7FFFFFF0u;
+				REQUIRE(len > 400 && fseek(fd, (320 + (len - 320) / 2) & ~3l, SEEK_SET) == 0 && fwrite(&junk, 4, 1, fd) == 1);
+				fclose(fd);
+				Q = NULL;
+				REQUIRE(blz_prepared_load(cpath, 77 + (uint64_t)nranks, &Q) != BLZ_OK && Q == NULL);
+				fd = fopen(cpath, "r+");
+				uint64_t huge = (uint64_t)1 << 40;
+				for (long off = 8 * 20; off < 8 * 34; off += 8) {	/* the offset words of the header */
+					REQUIRE(fseek(fd, off, SEEK_SET) == 0 && fwrite(&huge, 8, 1, fd) == 1);
+				}
+				fclose(fd);
+				REQUIRE(blz_prepared_load(cpath, 77 + (uint64_t)nranks, &Q) != BLZ_OK && Q == NULL);
+			}
 			FILE *fc = fopen(cpath, "r+");
 			REQUIRE(fc && ftruncate(fileno(fc), 100) == 0);
 			fclose(fc);
@@ -152,6 +172,89 @@ int main(int argc, char **argv)
 	matrix_round(&P, primes[2], scratch);
 	blz_coo_free(&P);
 	REQUIRE(blz_synth_structured(100, 100, 400, 3, 0, 7, 60, 60, 64, &P) != BLZ_OK);	/* percentages above 100 */
+
+	/* round 3: a rank's share generated and prepared alone (blz_synth_coo_part, blz_prepare_rank): every rank of 1, 3 and 8,
+	 * both orientations, gathering and short-side slabs; bad ranges and foreign entries refused */
+	{
+		const int64_t R = 30000, C = 4000, NZ = 150000;
+		for (int nranks = 1; nranks <= 8; nranks += (nranks == 1 ? 2 : 5))
+			for (int right = 0; right < 2; right++) {
+				int64_t rb[9], cb[9];
+				for (int g = 0; g <= nranks; g++) {
+					rb[g] = R * g / nranks;
+					cb[g] = C * g / nranks;
+				}
+				for (int rank = 0; rank < nranks; rank++) {
+					blz_coo rp_, cp_;
+					REQUIRE(blz_synth_coo_part(R, C, NZ, 0xBEEF, 0, primes[2], rb[rank], rb[rank + 1], 0, C, &rp_) == BLZ_OK);
+					REQUIRE(blz_synth_coo_part(R, C, NZ, 0xBEEF, 0, primes[2], 0, R, cb[rank], cb[rank + 1], &cp_) == BLZ_OK);
+					blz_prepared *Q = NULL;
+					REQUIRE(blz_prepare_rank(&rp_, &cp_, R, C, NZ, right, rank, nranks, nranks > 1 ? 2 : 1, rb, cb, &Q) == BLZ_OK);
+					for (int t = 0; t < 2; t++) {
+						blz_csr a, sh;
+						REQUIRE(blz_prepared_slab(Q, rank, t, &a) == BLZ_OK);
+						REQUIRE(a.row_ptr[a.rows] == (uint32_t)a.nnz);
+						for (int64_t k = 0; k < a.nnz; k++)
+							REQUIRE(a.col_idx[k] >= 0 && a.col_idx[k] < a.cols);
+						blz_csr_free(&a);
+						REQUIRE(blz_prepared_slab_short(Q, rank, t, &sh) == BLZ_OK);
+						blz_csr_free(&sh);
+						if (nranks > 1)
+							REQUIRE(blz_prepared_slab(Q, (rank + 1) % nranks, t, &a) != BLZ_OK);
+					}
+					REQUIRE(blz_prepared_save(Q, "/dev/null", 1) != BLZ_OK);
+					blz_prepared_free(Q);
+					if (nranks > 1) {	/* the rows of another rank are refused, not misfiled */
+						Q = NULL;
+						REQUIRE(blz_prepare_rank(&rp_, &cp_, R, C, NZ, right, (rank + 1) % nranks, nranks, 1, rb, cb, &Q) != BLZ_OK && Q == NULL);
+					}
+					blz_coo_free(&rp_);
+					blz_coo_free(&cp_);
+				}
+			}
+		blz_coo bad;
+		REQUIRE(blz_synth_coo_part(R, C, NZ, 1, 0, 7, 10, R + 1, 0, C, &bad) != BLZ_OK);
+		REQUIRE(blz_synth_coo_part(R, C, NZ, 1, 0, 7, 5, 5, 0, C, &bad) == BLZ_OK && bad.nnz == 0);
+		blz_coo_free(&bad);
+	}
+	/* round 3: the iterated-sweeps ordering, chosen on a band matrix whose rows and columns are scrambled */
+	{
+		const int64_t R = 20000, per = 12, band = 300;
+		blz_coo B = { R, R, R * per, malloc(sizeof(int32_t) * (size_t)(R * per)), malloc(sizeof(int32_t) * (size_t)(R * per)),
+			      malloc(sizeof(uint32_t) * (size_t)(R * per)) };
+		int32_t *pr = malloc(sizeof(int32_t) * (size_t)R), *pc = malloc(sizeof(int32_t) * (size_t)R);
+		REQUIRE(B.i && B.j && B.x && pr && pc);
+		uint64_t st = 12345;
+		for (int64_t r = 0; r < R; r++)
+			pr[r] = pc[r] = (int32_t)r;
+		for (int64_t r = R - 1; r > 0; r--) {	/* two shuffles */
+			st = st * 6364136223846793005ull + 1442695040888963407ull;
+			int64_t q = (int64_t)((st >> 33) % (uint64_t)(r + 1));
+			int32_t t_ = pr[r]; pr[r] = pr[q]; pr[q] = t_;
+			st = st * 6364136223846793005ull + 1442695040888963407ull;
+			q = (int64_t)((st >> 33) % (uint64_t)(r + 1));
+			t_ = pc[r]; pc[r] = pc[q]; pc[q] = t_;
+		}
+		for (int64_t r = 0; r < R; r++)
+			for (int64_t k = 0; k < per; k++) {
+				st = st * 6364136223846793005ull + 1442695040888963407ull;
+				const int64_t c = (r + (int64_t)((st >> 33) % (uint64_t)band) - band / 2 + R) % R;
+				B.i[r * per + k] = pr[r];
+				B.j[r * per + k] = pc[c];
+				B.x[r * per + k] = 1;
+			}
+		int32_t *r2 = malloc(sizeof(int32_t) * (size_t)R), *c2 = malloc(sizeof(int32_t) * (size_t)R);
+		int64_t hot[2] = { 0, 0 };
+		double share[2], loc[2];
+		int kind = -1;
+		REQUIRE(r2 && c2 && blz_reorder_auto(&B, r2, c2, hot, 0.25, share, 2, loc, &kind) == BLZ_OK);
+		REQUIRE(kind == 3 && loc[0] < 0.7 && loc[1] < 0.7);
+		free(r2);
+		free(c2);
+		free(pr);
+		free(pc);
+		blz_coo_free(&B);
+	}
 
 	/* RNG, kernel writer, checker (zero block, wrong block, bad shapes), both word widths */
 	const int n = 4;
