@@ -1912,24 +1912,60 @@ __device__ static u64 dev_invmod(u64 a, u64 p)
  * 60 squarings and 10 products along the chain 1, 2, 3, 6, 12, 24, 48, 54, 57, 59 (exponents 2^k - 1) do it.  The
  * inverse mod a prime is unique, so the word is the one the extended Euclid returns; a serial chain of Mersenne
  * multiplications has no 64-bit division in it (about 36 of them in the Euclid, each some hundred instructions here). */
+/* x^2 mod 2^61 - 1 for x < 2^61 from three 32 x 32 products: x = x1 2^32 + x0 (x1 < 2^29), x^2 = x0^2 + x0 x1 2^33 + x1^2 2^64,
+ * and 2^61 = 1: x1^2 2^64 = 8 x1^2 (< 2^61); x0 x1 2^33 with x0 x1 = mh 2^28 + ml is mh + ml 2^33 (< 2^61); x0^2 folds once.
+ * About half the instructions of the general 128-bit product and fold: the 60 squarings of the inversion below were 4.1 of the
+ * semi-inverse kernel's 18 us (in-kernel clock, round 3). */
+MODP_DEV u64 sqrmod61(u64 x)
+{
+	const u64 P = (1ull << 61) - 1;
+	const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+	const u64 lo = (u64)x0 * x0, mid = (u64)x0 * x1, hi = (u64)x1 * x1;
+	const u64 t = (lo & P) + (lo >> 61) + (mid >> 28) + ((mid & ((1ull << 28) - 1)) << 33) + (hi << 3);	/* < 4 * 2^61 */
+	const u64 r = (t & P) + (t >> 61);
+	return r >= P ? r - P : r;
+}
+
+/* x y mod 2^61 - 1 for RESIDUES x, y < 2^61, from four 32 x 32 products in the same way (x1, y1 < 2^29: x1 y1 2^64 = 8 x1 y1;
+ * the middle terms x0 y1 + x1 y0 = mh 2^29 + ml times 2^32 are mh + ml 2^32) */
+MODP_DEV u64 mulmod61_res(u64 x, u64 y)
+{
+	const u64 P = (1ull << 61) - 1;
+	const u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+	const u64 lo = (u64)x0 * y0, mid = (u64)x0 * y1 + (u64)x1 * y0, hi = (u64)x1 * y1;	/* mid < 2^62 */
+	const u64 t = (lo & P) + (lo >> 61) + (mid >> 29) + ((mid & ((1ull << 29) - 1)) << 32) + (hi << 3);	/* < 4 * 2^61 */
+	const u64 r = (t & P) + (t >> 61);
+	return r >= P ? r - P : r;
+}
+
 __device__ static u64 dev_invmod_mers61(u64 a, const ModP &m)
 {
+	(void)m;
 	auto sqn = [&](u64 x, int k) {
 		for (int i = 0; i < k; i++)
-			x = mulmod<61>(x, x, m);
+			x = sqrmod61(x);
 		return x;
 	};
 	const u64 x1 = a;
-	const u64 x2 = mulmod<61>(sqn(x1, 1), x1, m);
-	const u64 x3 = mulmod<61>(sqn(x2, 1), x1, m);
-	const u64 x6 = mulmod<61>(sqn(x3, 3), x3, m);
-	const u64 x12 = mulmod<61>(sqn(x6, 6), x6, m);
-	const u64 x24 = mulmod<61>(sqn(x12, 12), x12, m);
-	const u64 x48 = mulmod<61>(sqn(x24, 24), x24, m);
-	const u64 x54 = mulmod<61>(sqn(x48, 6), x6, m);
-	const u64 x57 = mulmod<61>(sqn(x54, 3), x3, m);
-	const u64 x59 = mulmod<61>(sqn(x57, 2), x2, m);
-	return mulmod<61>(sqn(x59, 2), x1, m);
+	const u64 x2 = mulmod61_res(sqn(x1, 1), x1);
+	const u64 x3 = mulmod61_res(sqn(x2, 1), x1);
+	const u64 x6 = mulmod61_res(sqn(x3, 3), x3);
+	const u64 x12 = mulmod61_res(sqn(x6, 6), x6);
+	const u64 x24 = mulmod61_res(sqn(x12, 12), x12);
+	const u64 x48 = mulmod61_res(sqn(x24, 24), x24);
+	const u64 x54 = mulmod61_res(sqn(x48, 6), x6);
+	const u64 x57 = mulmod61_res(sqn(x54, 3), x3);
+	const u64 x59 = mulmod61_res(sqn(x57, 2), x2);
+	return mulmod61_res(sqn(x59, 2), x1);
+}
+
+/* product of two residues with the lean form where the prime has one */
+template <int MERS>
+MODP_DEV u64 mulres(u64 x, u64 y, const ModP &m)
+{
+	if (MERS == 61)
+		return mulmod61_res(x, y);
+	return mulmod<MERS>(x, y, m);
 }
 
 /* ... and for p = 2^31 - 1: p - 2 = 2^31 - 3 is 29 ones, a zero and a one: 30 squarings and 8 products along
@@ -2091,18 +2127,29 @@ k_semi_inverse(const u64 *__restrict__ sums, u64 *__restrict__ small, DevCtl *__
 		A[e] = x;
 	}
 	u64 sel = 0, dbits = 0;
-	__syncthreads();
-	ff_sweep<MERS>(A, nullptr, nullptr, n, G, m, &sel);		/* phase 1, :349-382: which columns */
-	for (int e = lane; e < nn; e += T) {				/* :384-388 */
-		const int i = e / n, j = e % n;
-		const bool both = ((sel >> i) & 1) && ((sel >> j) & 1);
-		A[e] = both ? vtAv[e] : 0;
-		Wm[e] = (i == j && ((sel >> i) & 1)) ? 1 : 0;
-	}
+	/* one sweep on the unmasked matrix while every column pivots (see k_semi_inverse_reg); the reference's two otherwise */
+	for (int e = lane; e < nn; e += T)
+		Wm[e] = (e / n == e % n) ? 1 : 0;
 	if (lane < n)
 		S[lane] = 1;
 	__syncthreads();
-	const int npiv = ff_sweep<MERS>(A, Wm, S, n, G, m, &dbits);	/* phase 2, :389-436 */
+	int npiv = ff_sweep<MERS>(A, Wm, S, n, G, m, &dbits);
+	if (npiv != n) {
+		for (int e = lane; e < nn; e += T)
+			A[e] = vtAv[e];
+		__syncthreads();
+		ff_sweep<MERS>(A, nullptr, nullptr, n, G, m, &sel);		/* phase 1, :349-382: which columns */
+		for (int e = lane; e < nn; e += T) {				/* :384-388 */
+			const int i = e / n, j = e % n;
+			const bool both = ((sel >> i) & 1) && ((sel >> j) & 1);
+			A[e] = both ? vtAv[e] : 0;
+			Wm[e] = (i == j && ((sel >> i) & 1)) ? 1 : 0;
+		}
+		if (lane < n)
+			S[lane] = 1;
+		__syncthreads();
+		npiv = ff_sweep<MERS>(A, Wm, S, n, G, m, &dbits);	/* phase 2, :389-436 */
+	}
 	/* 1/s_i for all rows from one inversion: Pre[i] = s_0..s_i, then walk back */
 	if (lane == 0) {
 		u64 run = 1;
@@ -2269,7 +2316,7 @@ __device__ static int ff_sweep_reg(u64 &a, u64 *w, u64 *s, int n, const ModP &m,
 				*w = acc_reduce<MERS>(acc, m);
 			}
 			if (s)
-				*s = mulmod<MERS>(*s, pv, m);
+				*s = mulres<MERS>(*s, pv, m);
 		}
 	}
 	*mask = bits;
@@ -2306,13 +2353,23 @@ k_semi_inverse_reg(const u64 *__restrict__ sums, u64 *__restrict__ small, DevCtl
 			vtAv[e] = x0;
 			vtAAv[e] = y0;
 		}
+		/* The reference sweeps twice (:349-382 finds the set of columns that pivot, :389-436 eliminates again on the matrix
+		 * masked to that set, carrying the identity).  While vtAv is non-singular -- every iteration but the last few -- the
+		 * set is every column and the mask changes nothing, so the second sweep on the UNMASKED matrix is both at once: it
+		 * performs the first sweep's operations on `a`, and finds n pivots exactly when the first sweep would.  Only when
+		 * it finds fewer are the reference's two sweeps run (round 3: 2.9 of the kernel's 18 us). */
 		u64 sel = 0, dbits = 0;
-		u64 a = x0;
-		ff_sweep_reg<MERS, LG>(a, nullptr, nullptr, n, m, &sel);			/* phase 1, :349-382 */
-		const bool both = valid && ((sel >> i) & 1) && ((sel >> k) & 1);
-		a = both ? x0 : 0;								/* :384-388 */
-		u64 w = (valid && i == k && ((sel >> i) & 1)) ? 1 : 0, s = 1;
-		const int npiv = ff_sweep_reg<MERS, LG>(a, &w, &s, n, m, &dbits);		/* phase 2, :389-436 */
+		u64 a = x0, w = (valid && i == k) ? 1 : 0, s = 1;
+		int npiv = ff_sweep_reg<MERS, LG>(a, &w, &s, n, m, &dbits);
+		if (npiv != n) {
+			a = x0;
+			ff_sweep_reg<MERS, LG>(a, nullptr, nullptr, n, m, &sel);		/* phase 1, :349-382 */
+			const bool both = valid && ((sel >> i) & 1) && ((sel >> k) & 1);
+			a = both ? x0 : 0;							/* :384-388 */
+			w = (valid && i == k && ((sel >> i) & 1)) ? 1 : 0;
+			s = 1;
+			npiv = ff_sweep_reg<MERS, LG>(a, &w, &s, n, m, &dbits);		/* phase 2, :389-436 */
+		}
 		/* one inversion for all row scalars: the lanes of row i multiply the OTHER rows' scalars (q), q * s_i is the product
 		 * of all of them -- the same in every lane --, and 1 / s_i = q / (that product): n + 2 products around the
 		 * inversion where the prefix walk had 3 n */
@@ -2321,13 +2378,13 @@ k_semi_inverse_reg(const u64 *__restrict__ sums, u64 *__restrict__ small, DevCtl
 		for (int r = 0; r < G; r++) {
 			const u64 sr = readlane64(s, r << LG);
 			if (r < n) {
-				const u64 t = mulmod<MERS>(q, sr, m);
+				const u64 t = mulres<MERS>(q, sr, m);
 				q = r == i ? q : t;
 			}
 		}
-		const u64 all = readlane64(mulmod<MERS>(q, s, m), 0);
-		const u64 mine = mulmod<MERS>(dev_invmod_any<MERS>(all, m), q, m);
-		const u64 wn = valid ? mulmod<MERS>(w, mine, m) : 0;
+		const u64 all = readlane64(mulres<MERS>(q, s, m), 0);
+		const u64 mine = mulres<MERS>(dev_invmod_any<MERS>(all, m), q, m);
+		const u64 wn = valid ? mulres<MERS>(w, mine, m) : 0;
 		if (valid)
 			winv[e] = wn;
 		if (lane < n)
