@@ -538,6 +538,7 @@ static int upload_csr(blz_ctx *c, const blz_csr &H, DevCsr &D, int64_t hot_rows 
 		D.kept_mean = mean;
 	}
 	D.outlier_share = H.nnz > 0 ? 1.0 - (double)kept_nnz / (double)H.nnz : 0.0;
+	D.tail_batch = D.locality < 0.6 || H.nnz < 4000000;
 	D.n_heavy = (int)heavy.size();
 	D.n_multi = (int)multi.size();
 	if (D.n_heavy) {

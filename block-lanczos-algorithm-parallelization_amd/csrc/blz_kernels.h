@@ -38,6 +38,8 @@ struct DevCsr {
 	double kept_mean = -1.0;	/* mean length of the rows the streaming kernel keeps (< 0: nnz / rows) */
 	u32 heavy_thr = 0xFFFFFFFFu;
 	bool uneven = false;		/* row lengths vary a lot (std > mean/2): the SpMV wants more resident waves */
+	bool tail_batch = false;	/* k_spmv / k_spmv_dot take a row's 1-3 left-over entries as one predicated batch (gathers that hit, or a
+					 * product that is a few launches' worth of latency) */
 	double outlier_share = 0.0;	/* share of the entries in rows above heavy_thr (the outlier launches take them) */
 	double locality = 1.0;		/* lines of the operand per gathered entry that the renumbering's sample found for this product (1: no reuse) */
 	/* plan of the LDS-staged streaming kernel (k_spmv_staged), made at upload by spmv_plan_staged() */

@@ -97,8 +97,13 @@ MODP_DEV u64 shfl_xor64(u64 x, int mask)
  * output word, one coalesced row store.  No atomics, deterministic.
  */
 
-/* acc += sum over entries [k, e) of val * X[col, xl]; `stride` = words per block row */
-template <typename W>
+/* acc += sum over entries [k, e) of val * X[col, xl]; `stride` = words per block row.
+ * TAILB: the 1-3 entries left over after the batches of four go as ONE predicated batch (a slot past the end re-reads the
+ * row's last entry and is switched off by a zero multiplier) instead of one dependent index load + gather per entry.  It
+ * shortens the dependent chain of a row -- relat8 shape, 15 us products: 17.0 -> 15.8 us; structured workload, gathers that
+ * hit: 663 -> 647 us -- and costs the fabric-bound uniform shapes their dead slots (GL7d19 shape: 656 -> 664 us), so the
+ * slab's plan asks for it only where the gathers hit or the product is a few launches' worth of latency (round 3). */
+template <typename W, bool TAILB = false>
 MODP_DEV void spmv_accumulate(Acc &acc, u32 k, u32 e, const int *__restrict__ ci, const u32 *__restrict__ va,
 			      const u32 *spal, const W *__restrict__ X, int stride, int xl)
 {
@@ -113,9 +118,22 @@ MODP_DEV void spmv_accumulate(Acc &acc, u32 k, u32 e, const int *__restrict__ ci
 			acc_mac32(acc, spal[p2 >> 24], x2);
 			acc_mac32(acc, spal[p3 >> 24], x3);
 		}
-		for (; k < e; k++) {
-			const u32 pk = (u32)ci[k];
-			acc_mac32(acc, spal[pk >> 24], X[(size_t)(pk & 0xFFFFFFu) * stride + xl]);
+		if (TAILB) {
+			if (k < e) {
+				const u32 last = e - 1;
+				const u32 q1 = k + 1 < e ? k + 1 : last, q2 = k + 2 < e ? k + 2 : last;
+				const u32 p0 = (u32)ci[k], p1 = (u32)ci[q1], p2 = (u32)ci[q2];
+				const W x0 = X[(size_t)(p0 & 0xFFFFFFu) * stride + xl], x1 = X[(size_t)(p1 & 0xFFFFFFu) * stride + xl];
+				const W x2 = X[(size_t)(p2 & 0xFFFFFFu) * stride + xl];
+				acc_mac32(acc, spal[p0 >> 24], x0);
+				acc_mac32(acc, k + 1 < e ? spal[p1 >> 24] : 0u, x1);
+				acc_mac32(acc, k + 2 < e ? spal[p2 >> 24] : 0u, x2);
+			}
+		} else {
+			for (; k < e; k++) {
+				const u32 pk = (u32)ci[k];
+				acc_mac32(acc, spal[pk >> 24], X[(size_t)(pk & 0xFFFFFFu) * stride + xl]);
+			}
 		}
 	} else if (va) {
 		for (; k + 4 <= e; k += 4) {
@@ -128,8 +146,21 @@ MODP_DEV void spmv_accumulate(Acc &acc, u32 k, u32 e, const int *__restrict__ ci
 			acc_mac32(acc, a2, x2);
 			acc_mac32(acc, a3, x3);
 		}
-		for (; k < e; k++)
-			acc_mac32(acc, va[k], X[(size_t)ci[k] * stride + xl]);
+		if (TAILB) {
+			if (k < e) {
+				const u32 last = e - 1;
+				const u32 q1 = k + 1 < e ? k + 1 : last, q2 = k + 2 < e ? k + 2 : last;
+				const int c0 = ci[k], c1 = ci[q1], c2 = ci[q2];
+				const u32 a0 = va[k], a1 = va[q1], a2 = va[q2];
+				const W x0 = X[(size_t)c0 * stride + xl], x1 = X[(size_t)c1 * stride + xl], x2 = X[(size_t)c2 * stride + xl];
+				acc_mac32(acc, a0, x0);
+				acc_mac32(acc, k + 1 < e ? a1 : 0u, x1);
+				acc_mac32(acc, k + 2 < e ? a2 : 0u, x2);
+			}
+		} else {
+			for (; k < e; k++)
+				acc_mac32(acc, va[k], X[(size_t)ci[k] * stride + xl]);
+		}
 	} else {
 		for (; k + 4 <= e; k += 4) {
 			const int c0 = ci[k], c1 = ci[k + 1], c2 = ci[k + 2], c3 = ci[k + 3];
@@ -140,8 +171,20 @@ MODP_DEV void spmv_accumulate(Acc &acc, u32 k, u32 e, const int *__restrict__ ci
 			acc_add(acc, x2);
 			acc_add(acc, x3);
 		}
-		for (; k < e; k++)
-			acc_add(acc, X[(size_t)ci[k] * stride + xl]);
+		if (TAILB) {
+			if (k < e) {
+				const u32 last = e - 1;
+				const u32 q1 = k + 1 < e ? k + 1 : last, q2 = k + 2 < e ? k + 2 : last;
+				const int c0 = ci[k], c1 = ci[q1], c2 = ci[q2];
+				const W x0 = X[(size_t)c0 * stride + xl], x1 = X[(size_t)c1 * stride + xl], x2 = X[(size_t)c2 * stride + xl];
+				acc_add(acc, x0);
+				acc_add(acc, k + 1 < e ? (u64)x1 : 0ull);
+				acc_add(acc, k + 2 < e ? (u64)x2 : 0ull);
+			}
+		} else {
+			for (; k < e; k++)
+				acc_add(acc, X[(size_t)ci[k] * stride + xl]);
+		}
 	}
 }
 
@@ -266,7 +309,7 @@ static void launch_heavy(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, 
 				   partial, slot0 + (int)(hb + cb), ctl);
 }
 
-template <typename W, int G, int MERS>
+template <typename W, int G, int MERS, bool TAILB>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
        const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, long long rows, int n, int split_log2,
@@ -308,7 +351,7 @@ k_spmv(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__rest
 		}
 		Acc acc;
 		acc_zero(acc);
-		spmv_accumulate<W>(acc, k, e, ci, va, spal, X, n, xl);
+		spmv_accumulate<W, TAILB>(acc, k, e, ci, va, spal, X, n, xl);
 		for (int off = G; off < (G << split_log2); off <<= 1)
 			acc_add_acc(acc, shfl_xor64(acc.lo, off), shfl_xor64(acc.hi, off));
 		if (lane < n && part == 0) {
@@ -393,9 +436,14 @@ static hipError_t spmv_dispatch(const KernelCfg &c, const DevCsr &A, const W *X,
 	}
 #define SPMV_CASE(GG)                                                                                             \
 	case GG:                                                                                                  \
-		hipLaunchKernelGGL((k_spmv<W, GG, MERS>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr,  \
-				   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, accum,     \
-				   A.heavy_thr, c.m, xr, ctl);                                                     \
+		if (A.tail_batch)                                                                                 \
+			hipLaunchKernelGGL((k_spmv<W, GG, MERS, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr,  \
+					   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, accum,   \
+					   A.heavy_thr, c.m, xr, ctl);                                                     \
+		else                                                                                              \
+			hipLaunchKernelGGL((k_spmv<W, GG, MERS, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, \
+					   A.col_idx, A.val, A.palette, X, Y, (long long)A.rows, c.n, split_log2, accum,   \
+					   A.heavy_thr, c.m, xr, ctl);                                                     \
 		if (A.n_heavy || A.n_medium)                                                                      \
 			launch_heavy<W, GG, MERS, false>(c, A, X, Y, (const W *)nullptr, accum, (u64 *)nullptr, 0,   \
 							 heavy_blocks(c, A, 1 << 30), ctl, s);                        \
@@ -706,7 +754,7 @@ k_block_dot_64(const W *__restrict__ V, const W *__restrict__ AV, long long rows
  * per lane cost more occupancy than the saved pass is worth (measured: 15.8 ms fused against 12.4 + 2.3 ms apart on
  * the config-5 shape), so that width runs k_spmv and k_block_dot_fast.
  */
-template <typename W, int MERS, int NT>
+template <typename W, int MERS, int NT, bool TAILB>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__restrict__ va,
 	   const u32 *__restrict__ pal, const W *__restrict__ X, W *__restrict__ Y, const W *__restrict__ Vd,
@@ -740,7 +788,7 @@ k_spmv_dot(const u32 *__restrict__ rp, const int *__restrict__ ci, const u32 *__
 		const u64 vi = Vd[(size_t)r * NT + lane];
 		Acc acc;
 		acc_zero(acc);
-		spmv_accumulate<W>(acc, k, e, ci, va, spal, X, NT, lane);
+		spmv_accumulate<W, TAILB>(acc, k, e, ci, va, spal, X, NT, lane);
 		if (accum)
 			acc_add(acc, Y[(size_t)r * NT + lane]);
 		const u64 y = acc_reduce<MERS>(acc, m);
@@ -914,8 +962,12 @@ static hipError_t spmv_dot_dispatch(const KernelCfg &c, const DevCsr &A, const W
 	*nblocks = (int)(blocks + hb + cb + mb);
 #define SPMV_DOT(NN)                                                                                                \
 	case NN:                                                                                                    \
-		hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
-				   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, A.heavy_thr, c.m, partial, xr, ctl); \
+		if (A.tail_batch)                                                                                   \
+			hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
+					   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, A.heavy_thr, c.m, partial, xr, ctl); \
+		else                                                                                                \
+			hipLaunchKernelGGL((k_spmv_dot<W, MERS, NN, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, A.row_ptr, A.col_idx, \
+					   A.val, A.palette, X, Y, Vd, (long long)A.rows, accum, A.heavy_thr, c.m, partial, xr, ctl); \
 		if (hb || mb)                                                                                       \
 			launch_heavy<W, NN, MERS, true>(c, A, X, Y, Vd, accum, partial, (int)blocks, hb, ctl, s);      \
 		break;
