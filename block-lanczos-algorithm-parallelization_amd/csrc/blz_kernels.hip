@@ -2622,10 +2622,7 @@ k_orthogonalize(W *__restrict__ V, const W *__restrict__ AV, W *__restrict__ P, 
  * p[r,j] with three coalesced loads, and receives v[r,k], p[r,k] by broadcast inside the group.
  * No LDS, no barrier: pure streaming with 3*NT 64x64-bit MACs per output pair.
  */
-/* PF: the next row's three loads are issued before this row's arithmetic.  At the sizes where the kernel is a stream over
- * hundreds of MB that costs a resident wave and 11 % (round 1); where it is a few rows per lane group and each of them a
- * dependent trip to L2 (relat8 shape: 345 k rows of 16 bytes, 2.6 rows per group) it hides one trip behind the other. */
-template <typename W, int MERS, int NT, bool PF = false>
+template <typename W, int MERS, int NT>
 __global__ void __launch_bounds__(BLOCK)
 k_orthogonalize_fast(W *__restrict__ V, const W *__restrict__ AV, W *__restrict__ P, long long rows, ModP m,
 		     const u64 *__restrict__ small, const DevCtl *__restrict__ ctl)
@@ -2645,31 +2642,9 @@ k_orthogonalize_fast(W *__restrict__ V, const W *__restrict__ AV, W *__restrict_
 	const bool dj = small[3 * NN + j] != 0;
 	const long long g0 = (long long)blockIdx.x * GPB + t / NT, ng = (long long)gridDim.x * GPB;
 	const int src0 = gbase * 4;			/* byte address of lane 0 of the group for ds_bpermute */
-	u64 nv = 0, na = 0, np_ = 0;
-	if (PF && g0 < rows) {
-		const size_t at0 = (size_t)g0 * NT + j;
-		nv = V[at0];
-		na = AV[at0];
-		np_ = P[at0];
-	}
 	for (long long r = g0; r < rows; r += ng) {
 		const size_t at = (size_t)r * NT + j;
-		u64 vv, aa, pp;
-		if (PF) {
-			vv = nv;
-			aa = na;
-			pp = np_;
-			if (r + ng < rows) {
-				const size_t at1 = (size_t)(r + ng) * NT + j;
-				nv = V[at1];
-				na = AV[at1];
-				np_ = P[at1];
-			}
-		} else {
-			vv = V[at];
-			aa = AV[at];
-			pp = P[at];
-		}
+		const u64 vv = V[at], aa = AV[at], pp = P[at];
 		typename std::conditional<sizeof(W) == 8, AccL, AccS>::type av, ap;
 		acc_set(av, dj ? aa : vv);
 		acc_set(ap, dj ? 0 : pp);
@@ -2848,16 +2823,10 @@ static hipError_t ortho_dispatch(const KernelCfg &c, W *V, const W *AV, W *P, in
 			blocks = fit;
 		if (blocks > cap)
 			blocks = cap;
-		/* a few rows per lane group, each a dependent trip to L2: prefetch the next one (the in-place update is row-local) */
-		const bool pf = (long long)rows * n * (long long)sizeof(W) < (64ll << 20);
 #define ORTHO_FAST(NN)                                                                                               \
 	case NN:                                                                                                     \
-		if (pf)                                                                                              \
-			hipLaunchKernelGGL((k_orthogonalize_fast<W, MERS, NN, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, P, \
-					   (long long)rows, c.m, small, ctl);                                         \
-		else                                                                                                 \
-			hipLaunchKernelGGL((k_orthogonalize_fast<W, MERS, NN, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, P, \
-					   (long long)rows, c.m, small, ctl);                                         \
+		hipLaunchKernelGGL((k_orthogonalize_fast<W, MERS, NN>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, V, AV, P, \
+				   (long long)rows, c.m, small, ctl);                                                 \
 		break;
 		switch (n) {
 			ORTHO_FAST(1)
