@@ -270,22 +270,77 @@ def measure(blz, torch, dist, ctx, info, w, steps, warmup, repeats):
                            "spmv2": dict(zip(("rows", "share"), ctx.panel_rows(right)))})
 
 
+def first_spmv_kernel(name):
+    """rocprofv3's kernel name -> is it the plain (no fused block_dot) SpMV, i.e. the first product of a step"""
+    name = name.split("(")[0].replace("void ", "")
+    if name.startswith("k_spmv<"):
+        return True
+    if name.startswith("k_spmv_staged<") or name.startswith("k_spmv_panel<"):
+        targs = [a.strip() for a in name[name.index("<") + 1:].rstrip(">").split(",")]
+        return len(targs) > 3 and targs[3] == "false"        # <W, G, MERS, DOT, ...>
+    return False
+
+
 def spmv_traffic(workload, world):
     """HBM-side traffic of the first SpMV's kernel from the committed rocprofv3 PMC passes of this same command
-    (tools/gpu_profile.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs; bench.py cannot collect PMCs itself)."""
+    (tools/gpu_profile.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs).  The default run measures it again itself
+    (live_traffic below) and keeps this figure beside it as the cross-check."""
     tpath = os.path.join(ROOT, "profiles", f"traffic_{workload}_n{world}.json")
     if not os.path.exists(tpath):
         return None, None
     for name, rec in json.load(open(tpath)).items():
-        plain = name.startswith("k_spmv<") or (name.startswith("k_spmv_staged<") and ", false," in name) \
-            or (name.startswith("k_spmv_panel<") and ", false," in name)
-        if plain and "FETCH_SIZE_bytes_per_launch" in rec and "WRITE_SIZE_bytes_per_launch" in rec:
+        if first_spmv_kernel(name) and "FETCH_SIZE_bytes_per_launch" in rec and "WRITE_SIZE_bytes_per_launch" in rec:
             # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE = TCC_EA0_RDREQ x 64 B although every request is a
             # 128-byte line fill, so it is doubled; WRITE_SIZE is exact.  profiles/r01_v6_gl7d19_pmc_l2_fabric.txt and
             # profiles/r02_ubench2_pmc.txt confirm it: every L2->fabric read request of a gather is tallied under
             # TCC_EA0_RDREQ_128B, whatever the allocation kind or load policy.
             return 2 * rec["FETCH_SIZE_bytes_per_launch"] + rec["WRITE_SIZE_bytes_per_launch"], os.path.relpath(tpath, ROOT)
     return None, None
+
+
+def under_profiler():
+    return any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def live_traffic(workload, limit_s=150):
+    """The roofline's `traffic` measured by THIS run: two child processes of this same program under rocprofv3, `--pmc
+    FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (MI355X_MICROARCH.md, HBM section) with nothing else traced, a few
+    steps each; per launch of the first SpMV's kernel: 2 x FETCH_SIZE + WRITE_SIZE, both x 1024 bytes (same corrections as
+    spmv_traffic).  Children, never an exec: this process has initialised the GPU.  Each pass has a hard limit; a pass that
+    fails or is killed ends the measurement (no further GPU step after a kill) and the caller keeps the committed figure."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    got, t0 = {}, time.time()
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["timeout", "-k", "5", str(limit_s), prof, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(td, ctr), "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "3", "--warmup", "1", "--repeats", "1",
+                   "--cpu-seconds", "0", "--ref-iterations", "0", "--extras", "0", "--live-traffic", "0"]
+            try:
+                rr = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=limit_s + 30)
+            except Exception as exc:
+                return {"error": f"{ctr} pass: {exc!r}"}
+            if rr.returncode != 0:
+                return {"error": f"{ctr} pass ended with {rr.returncode}: {(rr.stderr or '')[-200:]}"}
+            tot, cnt = 0.0, 0
+            for f in glob.glob(os.path.join(td, ctr, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == ctr and first_spmv_kernel(row["Kernel_Name"]):
+                        tot += float(row["Counter_Value"])
+                        cnt += 1
+            if not cnt:
+                return {"error": f"{ctr} pass: no launch of the first SpMV's kernel in the counter file"}
+            got[ctr] = (tot / cnt * 1024, cnt)
+    fetch, wr = got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+    return {"traffic": 2 * fetch + wr, "FETCH_SIZE_bytes_per_launch": fetch, "WRITE_SIZE_bytes_per_launch": wr,
+            "launches": got["FETCH_SIZE"][1], "seconds": time.time() - t0}
 
 
 def main():
@@ -302,6 +357,9 @@ def main():
     ap.add_argument("--extras", type=int, default=-1,
                     help="1/0: also run the other single-GPU workloads (relat9, relat8, config-5 quarter shape, structured); "
                          "default: only with the default workload at N=1")
+    ap.add_argument("--live-traffic", type=int, default=-1,
+                    help="1/0: measure roofline.traffic in this run (two rocprofv3 --pmc child passes of the same workload); "
+                         "default: only with the default workload at N=1 and not under a profiler")
     ap.add_argument("--dry-run", action="store_true",
                     help="print what would be started (for N > 1 without a launcher: the torch.distributed.run command) and exit")
     args = ap.parse_args()
@@ -746,6 +804,35 @@ def main():
                 del Me
             except Exception as exc:    # an extra never costs the headline line
                 out["extra"]["workloads"][name] = {"error": repr(exc)}
+
+    # ---- roofline.traffic from this run's own PMC passes (the last GPU work of the run); the committed figure stays beside it
+    want_live = (args.live_traffic == 1) or (args.live_traffic < 0 and args.workload == "gl7d19" and world == 1 and dist is None
+                                             and args.cpu_seconds > 0 and not under_profiler())
+    if want_live and verdict and rank == 0 and world == 1:
+        lt = live_traffic(args.workload)
+        rf = out["roofline"]
+        rf["traffic_committed"], rf["traffic_committed_source"] = rf["traffic"], rf["traffic_source"]
+        if "traffic" in lt:
+            rf["traffic"] = lt["traffic"]
+            rf["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this run, "
+                                    f"{lt['launches']} launches, 2 x FETCH_SIZE + WRITE_SIZE (gfx950: 64 B counted per 128-byte fill)")
+            rf["traffic_live"] = lt
+            if t_spmv_ms:
+                rf["traffic_GBps"] = lt["traffic"] / (t_spmv_ms * 1e-3) / 1e9
+                rf["traffic_frac_of_peak"] = rf["traffic_GBps"] / HBM_PEAK_GBPS
+        else:
+            rf["traffic_live"] = lt         # why not; the committed figure stands
+        # the same two passes for each extra workload, while every pass before it ended by itself
+        for name, rec in (out.get("extra", {}).get("workloads", {}).items() if "traffic" in lt else ()):
+            if "error" in rec:
+                continue
+            le = live_traffic(name)
+            rec["spmv1_traffic_committed"], rec["spmv1_traffic_committed_source"] = rec["spmv1_traffic"], rec["spmv1_traffic_source"]
+            rec["spmv1_traffic_live"] = le
+            if "traffic" not in le:
+                break
+            rec["spmv1_traffic"] = le["traffic"]
+            rec["spmv1_traffic_source"] = f"live: rocprofv3 --pmc child passes of this run, {le['launches']} launches"
 
     if rank == 0:
         sys.stdout.flush()

@@ -61,3 +61,27 @@ def test_self_launch_relays_the_exit_code_of_its_ranks():
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "no GPU visible" in r.stderr or "ChildFailedError" in r.stderr
+
+
+def test_the_roofline_kernel_is_picked_by_its_template_arguments(monkeypatch):
+    """roofline.traffic is the PMC figure of the plain SpMV (no fused block_dot): the fourth template argument of the staged /
+    panel kernels decides, not any `false` in the name (the later arguments have some too)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    yes = ["void k_spmv<unsigned long, 8, 61, false>(DevCsr, unsigned long const*)", "k_spmv<unsigned int, 4, 31>",
+           "k_spmv_staged<unsigned long, 8, 61, false, 0, 8, false, 2>", "void k_spmv_panel<unsigned long, 8, 61, false, 1>(int)"]
+    no = ["k_spmv_dot<unsigned long, 61, 8>", "k_spmv_staged<unsigned long, 16, 61, true, 0, 8, false, 1>",
+          "k_spmv_panel<unsigned long, 8, 61, true, 1>", "k_ortho_mfma<8, false>", "k_dot_finalize"]
+    assert all(bench.first_spmv_kernel(k) for k in yes) and not any(bench.first_spmv_kernel(k) for k in no)
+    # every committed traffic file names exactly one such kernel
+    for wl in ("gl7d19", "relat9", "relat8", "synth5q"):
+        d = json.load(open(os.path.join(ROOT, "profiles", f"traffic_{wl}_n1.json")))
+        assert sum(bench.first_spmv_kernel(k) for k in d) == 1, wl
+        assert bench.spmv_traffic(wl, 1)[0] > 0
+    # a run that is itself being profiled does not start profiler passes of its own
+    for k in [k for k in os.environ if k.startswith("ROCPROF")]:
+        monkeypatch.delenv(k)
+    monkeypatch.setenv("LD_PRELOAD", "")
+    assert not bench.under_profiler()
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    assert bench.under_profiler()
