@@ -186,6 +186,27 @@ def gather_ceiling(row_bytes, table_bytes):
     return (best[1], f"{os.path.relpath(path, ROOT)}: {best[2]}") if best else (None, None)
 
 
+def live_gather_ceiling(row_bytes, table_bytes, avg_len):
+    """The same ceiling measured on THIS box in THIS run (the fill rate differs by up to 10 % between the pool's boxes): the bare
+    gather loop of tools/gather_ceiling.hip -- index load, gather, add -- for this row size, an operand of this size and
+    output rows of this many gathers, as a child process (a few seconds).  Only for 64- and 128-byte block rows of 8-byte
+    words; returns the program's JSON or {"error": ...}."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "gather_ceiling")
+    if row_bytes not in (64, 128) or not os.path.exists(exe):
+        return {"error": "not measured (row size or tools/gather_ceiling missing)"}
+    count = 40 if table_bytes < 1e9 else 100          # million gathers per launch: ~1 ms / ~2 ms
+    cmd = ["timeout", "-k", "5", "60", exe, str(row_bytes), f"{max(table_bytes / 1e6, 1.0):.1f}", str(max(1, int(round(avg_len)))),
+           str(count)]
+    try:
+        rr = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=90)
+        if rr.returncode != 0:
+            return {"error": f"tools/gather_ceiling ended with {rr.returncode}: {(rr.stderr or rr.stdout)[-200:]}"}
+        return json.loads(rr.stdout.strip().splitlines()[-1])
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
 def measure(blz, torch, dist, ctx, info, w, steps, warmup, repeats):
     """Warm up, time `repeats` regions of exactly `steps` steps (barrier + synchronize on both sides, MAX over ranks),
     then the same steps once more with HIP-event spans per kernel class.  Returns the numbers of one workload."""
@@ -800,14 +821,34 @@ def main():
                     "gather_ceiling_per_s": ceil_e, "gather_ceiling_source": ceil_src,
                     "kernels_ms": {k_: v_["ms_mean"] for k_, v_ in re_["kernels"].items() if v_["ms_mean"]},
                     "setup_s": t_set,
+                    "ceiling_args": (we["n"] * re_["word"], re_["rows_v"] * we["n"] * re_["word"], re_["nnz1"] / max(re_["rows_t"], 1)),
                 }
                 del Me
             except Exception as exc:    # an extra never costs the headline line
                 out["extra"]["workloads"][name] = {"error": repr(exc)}
 
-    # ---- roofline.traffic from this run's own PMC passes (the last GPU work of the run); the committed figure stays beside it
     want_live = (args.live_traffic == 1) or (args.live_traffic < 0 and args.workload == "gl7d19" and world == 1 and dist is None
                                              and args.cpu_seconds > 0 and not under_profiler())
+    # ---- the gather ceiling of this box, by the bare loop, for the headline product and for each extra one
+    if want_live and verdict and rank == 0 and world == 1:
+        rf = out["roofline"]
+        lc = live_gather_ceiling(n * r["word"], r["rows_v"] * n * r["word"], r["nnz1"] / max(r["rows_t"], 1))
+        rf["gather_ceiling_live"] = lc
+        if "bare_8B_per_lane" in lc and rf["gathers_per_s"]:
+            top = max(lc["bare_8B_per_lane"], lc["bare_16B_per_lane"])
+            rf["gathers_frac_of_live_ceiling"] = rf["gathers_per_s"] / top
+            rf["gathers_frac_of_live_ceiling_with_output_rows"] = rf["gathers_per_s"] / max(lc["with_output_rows_8B_per_lane"],
+                                                                                           lc["with_output_rows_16B_per_lane"])
+        for name, rec in out.get("extra", {}).get("workloads", {}).items():
+            if "error" in rec or "ceiling_args" not in rec:
+                continue
+            le = live_gather_ceiling(*rec.pop("ceiling_args"))
+            rec["gather_ceiling_live"] = le
+            if "bare_8B_per_lane" in le:
+                top = max(le["bare_8B_per_lane"], le["bare_16B_per_lane"])
+                rec["gathers_frac_of_live_ceiling"] = rec["gathers_per_s"] / top
+
+    # ---- roofline.traffic from this run's own PMC passes (the last GPU work of the run); the committed figure stays beside it
     if want_live and verdict and rank == 0 and world == 1:
         lt = live_traffic(args.workload)
         rf = out["roofline"]
@@ -834,6 +875,8 @@ def main():
             rec["spmv1_traffic"] = le["traffic"]
             rec["spmv1_traffic_source"] = f"live: rocprofv3 --pmc child passes of this run, {le['launches']} launches"
 
+    for rec in out.get("extra", {}).get("workloads", {}).values():
+        rec.pop("ceiling_args", None)
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
