@@ -85,3 +85,17 @@ def test_the_roofline_kernel_is_picked_by_its_template_arguments(monkeypatch):
     assert not bench.under_profiler()
     monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
     assert bench.under_profiler()
+
+
+def test_the_ceiling_program_checks_its_arguments_before_it_touches_the_gpu():
+    """tools/gather_ceiling (built by `make tools`, i.e. by __graft_entry__.build()) is started by bench.py as a child; bad
+    arguments end it with 2 and no HIP call, and bench.py only asks for the row sizes it was written for."""
+    exe = os.path.join(ROOT, "tools", "gather_ceiling")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "block-lanczos-algorithm-parallelization_amd"), "tools"])
+    for bad in ([], ["64", "100"], ["48", "100", "10"], ["64", "0", "10"], ["128", "100", "0"], ["64", "100", "10", "5000"]):
+        r = subprocess.run([exe] + bad, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2 and not r.stdout, bad
+    sys.path.insert(0, ROOT)
+    import bench
+    assert "error" in bench.live_gather_ceiling(16, 5e6, 100)
