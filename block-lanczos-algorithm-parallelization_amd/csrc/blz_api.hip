@@ -56,6 +56,9 @@ Rccl g_rccl;
  * no dependency on it. */
 int rccl_load()
 {
+	/* the CLI's --gpus N has one thread per GPU, each asking for its communicator: one of them loads, the others wait */
+	static std::mutex load_mu;
+	std::lock_guard<std::mutex> lk(load_mu);
 	if (g_rccl.handle)
 		return BLZ_OK;
 	/* Prefer the RCCL that belongs to the ROCm installation this library was built against (the HIP runtime the

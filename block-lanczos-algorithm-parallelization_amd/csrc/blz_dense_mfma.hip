@@ -31,6 +31,7 @@
 #include "ortho_img.h"
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <cstdlib>
 
@@ -360,13 +361,18 @@ template <int NT, bool ST>
 static void ortho_mfma_shape(int *threads, int *per_cu)
 {
 	using G = OG<NT, ST>;
-	static int cached_t[64] = { 0 }, cached_k[64] = { 0 };
+	/* contexts of one process may live on several threads (loopback ranks, one thread per GPU in the CLI): the answer is the
+	 * same whoever computes it, the flag (k > 0) is published after the value it guards */
+	static std::atomic<int> cached_t[64], cached_k[64];
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	if (dev >= 0 && dev < 64 && cached_k[dev] > 0) {
-		*threads = cached_t[dev];
-		*per_cu = cached_k[dev];
-		return;
+	if (dev >= 0 && dev < 64) {
+		const int k_ = cached_k[dev].load(std::memory_order_acquire);
+		if (k_ > 0) {
+			*threads = cached_t[dev].load(std::memory_order_relaxed);
+			*per_cu = k_;
+			return;
+		}
 	}
 	int t = G::THREADS;
 	if (const char *e = getenv("BLZ_MFMA_BLOCK"))	/* experiments */
@@ -384,8 +390,8 @@ static void ortho_mfma_shape(int *threads, int *per_cu)
 	if (e && atoi(e) > 0 && atoi(e) < k)
 		k = atoi(e);
 	if (dev >= 0 && dev < 64) {
-		cached_t[dev] = t;
-		cached_k[dev] = k;
+		cached_t[dev].store(t, std::memory_order_relaxed);
+		cached_k[dev].store(k, std::memory_order_release);
 	}
 	*threads = t;
 	*per_cu = k;

@@ -11,6 +11,7 @@
 #include "ortho_img.h"
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #define BLOCK 256
@@ -1755,13 +1756,13 @@ static void panel_launch(const KernelCfg &c, const DevCsr &A, const W *X, W *Y, 
 		xr.begin[x] = A.xr_rows[0] < 0 ? A.rows * x / 8 : A.xr_rows[x];
 	const size_t lds = (size_t)A.panel_rows * G * sizeof(W);
 	auto kern = k_spmv_panel<W, G, MERS, DOT, VALS>;
-	static bool attr_set[64] = { false };	/* per instantiation and per device */
+	static std::atomic<bool> attr_set[64];	/* per instantiation and per device; several threads may ask (setting it twice is harmless) */
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+	if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
 		(void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_BYTES);
 		if (dev >= 0 && dev < 64)
-			attr_set[dev] = true;
+			attr_set[dev].store(true, std::memory_order_release);
 	}
 	hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PBLOCK), lds, s, A.row_ptr, (const u32 *)A.col_idx, A.val,
 			   A.palette, X, Y, Vd, accum, A.heavy_thr, c.m, partial, xr, (u32)A.panel_rows, ctl);
