@@ -206,3 +206,31 @@ def test_cli_with_several_contexts_on_one_gpu_reproduces_the_reference_hashes(tm
         assert hashlib.sha256(open(out, "rb").read()).hexdigest() == c["out_sha256"], tag
         ran += 1
     assert ran >= 2
+
+
+def test_a_checkpoint_written_by_three_contexts_is_resumed_by_two_and_by_one(tmp_path):
+    """The checkpoint file holds whole blocks in the file's row order (assembled from the ranks' slabs), so the number of GPUs that
+    wrote it does not bind the run that resumes it: 37 iterations on 3 contexts, then the rest on 2 contexts and on 1, against
+    the uninterrupted single-GPU run -- byte-identical kernel files (openMP/lanczos_modp.c:571-676 is the reference's
+    checkpoint; it has one process, so no such question)."""
+    import subprocess
+    exe = os.path.join(ROOT, "block-lanczos-algorithm-parallelization_amd", "lib", "lanczos_modp")
+    base = ["--matrix", os.path.join(GOLDEN, "rand3000x2000.mtx"), "--prime", "1073741789", "--n", "8"]
+    env = dict(os.environ, BLZ_LOOPBACK="1")
+
+    def run(args, cwd):
+        return subprocess.run([exe] + base + args, capture_output=True, text=True, timeout=600, env=env, cwd=str(cwd))
+    full = str(tmp_path / "full.mtx")
+    assert run(["--output-file", full], tmp_path).returncode == 0
+    work = tmp_path / "ck"
+    work.mkdir()
+    r = run(["--gpus", "3", "--checkpoint", "0", "--stop-after", "37"], work)
+    assert r.returncode == 0 and os.path.exists(work / "lanczos_modp.ckpt"), r.stdout + r.stderr
+    assert "after 37 iterations" in r.stdout
+    saved = open(work / "lanczos_modp.ckpt", "rb").read()
+    for gpus in (2, 1):
+        open(work / "lanczos_modp.ckpt", "wb").write(saved)
+        out = str(tmp_path / f"resumed{gpus}.mtx")
+        r = run(["--load-checkpoint", "--output-file", out] + (["--gpus", str(gpus)] if gpus > 1 else []), work)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert open(full, "rb").read() == open(out, "rb").read(), gpus
