@@ -280,3 +280,40 @@ def test_verify_mode_with_several_contexts(tmp_path, gpus):
         assert r.returncode == 0, r.stderr[-1500:]
         assert f"after {c['iterations']} iterations" in r.stdout
         assert hashlib.sha256(open(out, "rb").read()).hexdigest() == c["out_sha256"], tag
+
+
+REF_OMP = os.path.join(ROOT, "oracle", "_ref", "lanczos_modp_omp_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_OMP), reason="oracle/_ref not built (reference checkout absent)")
+def test_the_reference_text_checkpoint_both_ways_with_several_contexts(tmp_path):
+    """tests/test_gpu_cli.py::test_resume_from_the_reference_text_checkpoint with three contexts on this side: the reference's own
+    OpenMP binary (1 thread) starts the solve and writes v.txt tmp.txt Av.txt p.txt verbosity.txt (openMP/lanczos_modp.c:571-676),
+    three contexts finish it; then three contexts start one, export the text files (assembled from their slabs), and the
+    reference finishes it.  Both must end in the reference's uninterrupted result."""
+    import hashlib
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "block-lanczos-algorithm-parallelization_amd", "lib", "lanczos_modp")
+    mpath = os.path.join(GOLDEN, "rand300x200.mtx")
+    want = json.load(open(os.path.join(GOLDEN, "cli.json")))["rand300x200_p65537_n4_left"]["out_sha256"]
+    base = ["--matrix", mpath, "--prime", "65537", "--n", "4"]
+    env1 = dict(os.environ, OMP_NUM_THREADS="1")
+    work = tmp_path / "ref"
+    work.mkdir()
+    r = subprocess.run([REF_OMP] + base + ["--checkpoint", "0", "--stop-after", "10"], cwd=str(work), env=env1, capture_output=True, text=True)
+    assert r.returncode == 0 and os.path.exists(work / "v.txt")
+    out = str(tmp_path / "resumed.mtx")
+    r = subprocess.run([exe] + base + ["--gpus", "3", "--load-checkpoint", "--output-file", out], cwd=str(work),
+                       env=dict(os.environ, BLZ_LOOPBACK="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == want
+    work2 = tmp_path / "ours"
+    work2.mkdir()
+    r = subprocess.run([exe] + base + ["--gpus", "3", "--checkpoint", "0", "--stop-after", "10"], cwd=str(work2),
+                       env=dict(os.environ, BLZ_LOOPBACK="1", BLZ_REF_CHECKPOINT="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and os.path.exists(work2 / "p.txt"), r.stdout + r.stderr[-1500:]
+    out2 = str(tmp_path / "ref_resumed.mtx")
+    r = subprocess.run([REF_OMP] + base + ["--load-checkpoint", "--output-file", out2], cwd=str(work2), env=env1, capture_output=True, text=True)
+    assert r.returncode == 0
+    assert hashlib.sha256(open(out2, "rb").read()).hexdigest() == want
