@@ -95,7 +95,15 @@ static void measure(double mb, int len, long long count, int ncu, int row_bytes)
 	int *idx;
 	CHK(hipMalloc(&table, (size_t)rows * row_bytes));
 	CHK(hipMemset(table, 1, (size_t)rows * row_bytes));
-	CHK(hipMalloc(&y, (size_t)(nrows + 1) * row_bytes));
+	/* GC_Y_ALLOC=uncached|fine (experiment, profiles/r03_gather_ceiling_output_alloc.txt): the output rows in memory that the
+	 * L2 does not hold dirty -- does the write stream cost less when it never waits for an eviction? */
+	const char *ya = getenv("GC_Y_ALLOC");
+	if (ya && ya[0] == 'u')
+		CHK(hipExtMallocWithFlags((void **)&y, (size_t)(nrows + 1) * row_bytes, hipDeviceMallocUncached));
+	else if (ya && ya[0] == 'f')
+		CHK(hipExtMallocWithFlags((void **)&y, (size_t)(nrows + 1) * row_bytes, hipDeviceMallocFinegrained));
+	else
+		CHK(hipMalloc(&y, (size_t)(nrows + 1) * row_bytes));
 	CHK(hipMalloc(&out, 4096));
 	CHK(hipMalloc(&idx, (size_t)nrows * len * 4));
 	{
