@@ -99,3 +99,14 @@ def test_the_ceiling_program_checks_its_arguments_before_it_touches_the_gpu():
     sys.path.insert(0, ROOT)
     import bench
     assert "error" in bench.live_gather_ceiling(16, 5e6, 100)
+
+
+def test_a_failed_profiler_pass_is_reported_not_raised():
+    """bench.py measures roofline.traffic with two rocprofv3 child passes of itself; a pass that fails (here: no GPU, so the child
+    ends with an error) must come back as {"error": ...} -- the caller then keeps the committed figure and still prints its line --
+    and no second pass is started after a failed one."""
+    sys.path.insert(0, ROOT)
+    import bench
+    got = bench.live_traffic("relat8", limit_s=120)
+    assert set(got) == {"error"}, got
+    assert got["error"].startswith(("FETCH_SIZE pass", "rocprofv3 not found")), got
