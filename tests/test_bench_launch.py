@@ -105,6 +105,9 @@ def test_a_failed_profiler_pass_is_reported_not_raised():
     """bench.py measures roofline.traffic with two rocprofv3 child passes of itself; a pass that fails (here: no GPU, so the child
     ends with an error) must come back as {"error": ...} -- the caller then keeps the committed figure and still prints its line --
     and no second pass is started after a failed one."""
+    import pytest
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present: the pass would succeed (tests/test_gpu_*.py cover that side)")
     sys.path.insert(0, ROOT)
     import bench
     got = bench.live_traffic("relat8", limit_s=120)
