@@ -8,21 +8,25 @@
 extern "C" {
 #endif
 
+/* Helpers shared by the two halves of the library; not part of the ABI: libblz_hip.so exports what include/blz.h declares
+ * and nothing else (tests/test_host_abi.py checks both directions). */
+#define BLZ_LOCAL __attribute__((visibility("hidden")))
+
 /* printf-style; returns `code` so that callers can `return blz_fail(BLZ_EINVAL, "...")`. */
-int blz_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+BLZ_LOCAL int blz_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 /* Column indices of a CSR slab are rewritten from global rows of the source block to positions in the
  * gathered operand: a slab of `chunks` pieces of `piece` rows each; row q of rank g's slab lives at
  *     (q / piece) * (parts * piece) + g * piece + (q % piece)
  * i.e. piece-major, rank-major inside a piece, so that all-gather number k of equal pieces lands contiguously.
  * With chunks == 1 this is the rank-major padded layout; for one rank it is the identity. */
-void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t piece, int chunks);
-int blz_csr_split_columns(const blz_csr *A, int64_t width, int chunks, blz_csr *out);
+BLZ_LOCAL void blz_remap_columns(blz_csr *A, const int64_t *bounds, int parts, int64_t piece, int chunks);
+BLZ_LOCAL int blz_csr_split_columns(const blz_csr *A, int64_t width, int chunks, blz_csr *out);
 
-void blz_coo_relabel(const blz_coo *M, const int32_t *row_perm, const int32_t *col_perm, int32_t *new_i, int32_t *new_j);
+BLZ_LOCAL void blz_coo_relabel(const blz_coo *M, const int32_t *row_perm, const int32_t *col_perm, int32_t *new_i, int32_t *new_j);
 
 /* Rows [r0, r1) of A as a standalone CSR (deep copy). */
-int blz_csr_slab(const blz_csr *A, int64_t r0, int64_t r1, blz_csr *out);
+BLZ_LOCAL int blz_csr_slab(const blz_csr *A, int64_t r0, int64_t r1, blz_csr *out);
 
 /* the prepared matrix (include/blz.h: blz_prepare); arrays are malloc'ed, or live in the mmapped cache file when map != NULL */
 struct blz_prepared {

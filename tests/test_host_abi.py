@@ -29,6 +29,13 @@ def test_library_exports_every_declared_symbol():
     L = blz.lib()
     missing = [nm for nm in names if not hasattr(L, nm)]
     assert not missing, missing
+    # and the other direction: nothing named blz_* leaves the library that the header does not declare (helpers shared by the
+    # C and the HIP half are hidden, csrc/blz_internal.h)
+    import subprocess
+    so = os.path.join(ROOT, "block-lanczos-algorithm-parallelization_amd", "lib", "libblz_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("blz_")}
+    assert exported == set(names), sorted(exported ^ set(names))
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
